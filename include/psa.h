@@ -1,0 +1,146 @@
+/*
+ * psa.h -- C ABI of libpsa_hip: the MI355X (gfx950) replacement for the
+ * alignment-scoring call of ybiblow/Parallel-Sequence-Alignment.
+ *
+ * The reference scores, for one Seq2 against Seq1, every offset s and every
+ * mutant MS(n,k) (Seq2 with the characters at 1-based positions n < k removed)
+ * as the float32 left-to-right sum of 26x26 table entries and reports the first
+ * maximum in (n, k, offset) order.  This library returns the same n, k, offset
+ * and the same float32 bits.
+ *
+ * Citations: P/ = "Parallel Solution/", S/ = "Sequential Solution/" of the
+ * reference repository.
+ *
+ * All functions return PSA_OK (0) or a psa_status code unless stated otherwise;
+ * none of them exits the process except the drop-in shim psa_calc_best_score,
+ * which keeps the reference's print-and-exit behaviour.
+ */
+#ifndef PSA_H
+#define PSA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSA_TABLE_SIZE 676   /* 26 x 26, row = Seq1 residue, column = Seq2 residue (P/myProto.h:13) */
+#define PSA_MAX_SEQ2 8191    /* longest Seq2 the kernels are built for */
+
+typedef enum psa_status {
+  PSA_OK = 0,
+  PSA_ERR_ARG = 1,        /* NULL pointer, negative count, empty range */
+  PSA_ERR_SEQ2_SHORT = 2, /* len(Seq2) < 2: no mutant exists */
+  PSA_ERR_SEQ2_LONG = 3,  /* len(Seq2) - 2 > len(Seq1) (no offset) or len(Seq2) > PSA_MAX_SEQ2 */
+  PSA_ERR_RESIDUE = 4,    /* a character outside 'A'..'Z' (the reference indexes out of bounds, P/cudaFunctions.cu:218) */
+  PSA_ERR_HIP = 5,        /* a HIP runtime call failed; psa_last_error_text() has the message */
+  PSA_ERR_NO_DEVICE = 6,  /* no usable GPU */
+  PSA_ERR_STATE = 7,      /* Seq1 or the table has not been set on the context */
+  PSA_ERR_NOMEM = 8
+} psa_status;
+
+/* stages of one run; 0 means both */
+#define PSA_STAGE_ENUMERATE 1u /* score every (offset, mutant) candidate in fixed point */
+#define PSA_STAGE_RESOLVE 2u   /* float32-exact answer of the reference */
+
+/* One record per Seq2.  (n, k, offset, score) are what the reference prints
+ * (P/cFunctions.c:157, S/main.c:82); counts are the residue-class counts
+ * (identical, conservative, semi-conservative, other) of that winner.
+ * The enum_* fields describe the enumeration stage: every candidate is scored
+ * as the exact integer sum of table entries scaled by 2^enum_frac_bits and
+ * rounded to nearest; enum_exact is 2 when that equals the float32 arithmetic
+ * of the reference for every candidate (then both winners coincide), 1 when
+ * only the table is represented exactly, 0 otherwise, -1 if the stage did not
+ * run. */
+typedef struct psa_result {
+  int32_t n, k;
+  int32_t offset;
+  int32_t mutant_num;   /* 0-based mutant number as printed by P/cFunctions.c:153-157 */
+  float score;
+  uint32_t score_bits;
+  int32_t counts[4];
+  int32_t enum_n, enum_k, enum_offset;
+  int32_t enum_score;     /* fixed point, units of 2^-enum_frac_bits */
+  int32_t enum_frac_bits; /* -1: table too large for int32 fixed point */
+  int32_t enum_exact;
+  int32_t enum_counts[4];
+  int32_t status;         /* psa_status of this Seq2 */
+  int32_t reserved;
+  int64_t candidates;     /* (offsets in range) x len2 x (len2-1)/2 */
+} psa_result;
+
+typedef struct psa_ctx psa_ctx;     /* one per GPU; holds Seq1 and the table resident in HBM */
+typedef struct psa_batch psa_batch; /* a set of Seq2 resident in HBM, plus work lists and result buffers */
+
+/* ---- context ------------------------------------------------------------------
+ * Replaces the implicit device 0 and the per-call cudaMalloc/cudaMemcpy of Seq1
+ * and the table in calc_best_score_CUDA (P/cudaFunctions.cu:273-288). */
+int psa_device_count(void);
+int psa_init(int device, psa_ctx **out);
+void psa_shutdown(psa_ctx *ctx);
+int psa_set_seq1(psa_ctx *ctx, const char *seq1, int64_t len1);
+/* table built from four weights exactly as createCompMatrix does (P/cFunctions.c:55-76) */
+int psa_set_weights(psa_ctx *ctx, const float weights[4]);
+/* any 26x26 float table, the argument calc_best_score_CUDA receives (P/myProto.h:20) */
+int psa_set_table(psa_ctx *ctx, const float table[PSA_TABLE_SIZE]);
+
+/* ---- batches of Seq2 ------------------------------------------------------------
+ * Replaces the per-Seq2 loop around calc_best_score_CUDA (P/main.c:79-84, :128-135).
+ * len2 may be NULL (then every seq2[i] is NUL-terminated). */
+int psa_batch_create(psa_ctx *ctx, int n, const char *const *seq2, const int32_t *len2, psa_batch **out);
+/* one Seq2 restricted to offsets [s_begin, s_end): the shard of a long pair that one GPU owns */
+int psa_batch_create_range(psa_ctx *ctx, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end,
+                           psa_batch **out);
+/* launches the kernels on data already resident in HBM and waits for them */
+int psa_batch_run(psa_batch *b, uint32_t stages);
+/* copies the n records of the last run */
+int psa_batch_results(const psa_batch *b, psa_result *out);
+/* device time of the last run in milliseconds, from HIP events on the launch streams:
+ * the enumeration kernel(s) alone, and first launch to last completion */
+int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms);
+int psa_batch_size(const psa_batch *b);
+void psa_batch_destroy(psa_batch *b);
+
+/* create + run + results + destroy */
+int psa_score_batch(psa_ctx *ctx, int n, const char *const *seq2, const int32_t *len2, uint32_t stages,
+                    psa_result *out);
+int psa_score_range(psa_ctx *ctx, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end,
+                    uint32_t stages, psa_result *out);
+
+/* max-loc combine of the records that the shards of one long pair returned:
+ * highest float32 score, ties to the smallest (n, k, offset); likewise for the
+ * enumeration fields.  Pure host code; the transport between GPUs is the
+ * caller's (one all-gather of sizeof(psa_result) bytes per rank). */
+int psa_combine_results(const psa_result *parts, int nparts, psa_result *out);
+
+/* ---- the reference's host helpers ------------------------------------------------ */
+/* drop-in for  char* calc_best_score_CUDA(char*, char*, float*)  (P/myProto.h:20,
+ * P/cudaFunctions.cu:260-323): returns the malloc'd line
+ * "mutant num: %d, MS(%d,%d), score: %1.2f, offset: %d\n" (caller frees, P/main.c:83),
+ * echoes it on stdout (P/cudaFunctions.cu:321; PSA_SHIM_QUIET=1 silences it), and on
+ * any failure prints to stderr and exits like the reference's macros (P/cudaFunctions.cu:5-18). */
+char *psa_calc_best_score(const char *seq1, const char *seq2, const float *comp_matrix);
+/* createCompMatrix (P/cFunctions.c:55-64); size must be PSA_TABLE_SIZE */
+void psa_create_comp_matrix(float *arr, int size, const float *weights);
+/* findSimilarityWeight's class decision (P/cFunctions.c:67-100): 0 identical, 1 conservative,
+ * 2 semi-conservative, 3 other */
+int psa_residue_class(char a, char b);
+/* CPUGetNK (P/cFunctions.c:104-119): 1-based mutant number -> (n, k); closed form */
+void psa_get_nk(int64_t mutant_number, int len2, int *n, int *k);
+int64_t psa_mutant_number(int n, int k, int len2);
+/* the line calcBestScoreOmp formats (P/cFunctions.c:157); malloc'd, caller frees */
+char *psa_format_result(const psa_result *r);
+/* work split replacing calcPortion (P/cFunctions.c:49-52): assigns each Seq2 to one of
+ * nparts workers balancing the candidate counts; owner[i] in [0, nparts) */
+int psa_partition(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner);
+/* the reference's own split (first n/2 to worker 0, rest to worker 1) for comparison */
+void psa_calc_portion(int *portion, int num);
+
+const char *psa_strerror(int status);
+const char *psa_last_error_text(void);
+const char *psa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSA_H */

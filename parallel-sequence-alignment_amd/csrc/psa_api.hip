@@ -1,0 +1,504 @@
+// C ABI of libpsa_hip: contexts, batches, launch orchestration and the drop-in shim.
+// Citations: P/ = "Parallel Solution/", S/ = "Sequential Solution/".
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "psa_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+#define PSA_HIP(call)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      g_err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return PSA_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+template <class T>
+int upload(T **dptr, const std::vector<T> &h) {
+  *dptr = nullptr;
+  if (h.empty()) return PSA_OK;
+  PSA_HIP(hipMalloc((void **)dptr, h.size() * sizeof(T)));
+  PSA_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PSA_OK;
+}
+
+}  // namespace
+
+struct psa_ctx {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t st_enum = nullptr, st_res = nullptr;
+  unsigned char *d_seq1 = nullptr;
+  int64_t len1 = 0;
+  float table[PSA_TABLE_SIZE];
+  bool have_table = false, have_seq1 = false;
+  float *d_table_t = nullptr;          // [27][32] floats, [seq2 code][seq1 code]
+  unsigned char *d_class_t = nullptr;  // [27][32] class digits
+};
+
+struct psa_batch {
+  psa_ctx *ctx = nullptr;
+  int n = 0;
+  int max_len2 = 0;
+  int64_t total_offsets = 0;
+  int nvalid = 0;
+  std::vector<psa::SeqDesc> desc;
+  std::vector<psa_result> tmpl;  // per-Seq2 record with the host-known fields filled in
+  unsigned char *d_pool = nullptr;
+  psa::SeqDesc *d_desc = nullptr;
+  psa::SeqAcc *d_acc = nullptr;
+  unsigned *d_counters = nullptr;  // kEnumClasses work counters + the active-offset count
+  psa::Chunk *d_chunks[psa::kEnumClasses] = {};
+  int nchunks[psa::kEnumClasses] = {};
+  int grid[psa::kEnumClasses] = {};
+  psa::FwdBlock *d_fwd = nullptr;
+  int nfwd = 0;
+  float *d_fs = nullptr;
+  psa::ActiveOffset *d_active = nullptr;
+  psa_result *d_out = nullptr;
+  psa_result *h_out = nullptr;  // pinned
+  hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_init = nullptr, ev_res = nullptr;
+  hipEvent_t ev_b[psa::kEnumClasses] = {}, ev_e[psa::kEnumClasses] = {};
+  uint32_t last_stages = 0;
+  float enum_ms = 0.f, total_ms = 0.f;
+  bool ran = false;
+};
+
+extern "C" {
+
+const char *psa_last_error_text(void) { return g_err.c_str(); }
+
+int psa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int psa_init(int device, psa_ctx **out) {
+  if (!out) return PSA_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    g_err = "no HIP device visible";
+    return PSA_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) return PSA_ERR_ARG;
+  PSA_HIP(hipSetDevice(device));
+  psa_ctx *c = new (std::nothrow) psa_ctx();
+  if (!c) return PSA_ERR_NOMEM;
+  c->device = device;
+  hipDeviceProp_t prop;
+  PSA_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  PSA_HIP(hipStreamCreateWithFlags(&c->st_enum, hipStreamNonBlocking));
+  PSA_HIP(hipStreamCreateWithFlags(&c->st_res, hipStreamNonBlocking));
+  PSA_HIP(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
+  PSA_HIP(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
+  std::vector<unsigned char> cls(psa::kDevTable, 3);
+  for (int b = 0; b < 26; ++b)
+    for (int a = 0; a < 26; ++a) cls[b * psa::kRowStride + a] = (unsigned char)psa::residue_class_code(a, b);
+  PSA_HIP(hipMemcpy(c->d_class_t, cls.data(), cls.size(), hipMemcpyHostToDevice));
+  *out = c;
+  return PSA_OK;
+}
+
+void psa_shutdown(psa_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_seq1) (void)hipFree(c->d_seq1);
+  if (c->d_table_t) (void)hipFree(c->d_table_t);
+  if (c->d_class_t) (void)hipFree(c->d_class_t);
+  if (c->st_enum) (void)hipStreamDestroy(c->st_enum);
+  if (c->st_res) (void)hipStreamDestroy(c->st_res);
+  delete c;
+}
+
+int psa_set_seq1(psa_ctx *c, const char *seq1, int64_t len1) {
+  if (!c || !seq1) return PSA_ERR_ARG;
+  if (len1 < 0) len1 = (int64_t)std::strlen(seq1);
+  if (len1 < 1 || len1 > 0x7fff0000ll) return PSA_ERR_ARG;
+  std::vector<unsigned char> codes((size_t)len1);
+  for (int64_t i = 0; i < len1; ++i) {
+    unsigned char ch = (unsigned char)seq1[i];
+    if (ch < 'A' || ch > 'Z') return PSA_ERR_RESIDUE;
+    codes[(size_t)i] = ch - 'A';
+  }
+  PSA_HIP(hipSetDevice(c->device));
+  if (c->d_seq1) {
+    PSA_HIP(hipFree(c->d_seq1));
+    c->d_seq1 = nullptr;
+  }
+  PSA_HIP(hipMalloc((void **)&c->d_seq1, (size_t)len1));
+  PSA_HIP(hipMemcpy(c->d_seq1, codes.data(), (size_t)len1, hipMemcpyHostToDevice));
+  c->len1 = len1;
+  c->have_seq1 = true;
+  return PSA_OK;
+}
+
+int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
+  if (!c || !table) return PSA_ERR_ARG;
+  std::memcpy(c->table, table, sizeof c->table);
+  // device copy: transposed to [seq2 code][seq1 code], zero row and column for the padding code
+  std::vector<float> t(psa::kDevTable, 0.0f);
+  for (int a = 0; a < 26; ++a)
+    for (int b = 0; b < 26; ++b) t[b * psa::kRowStride + a] = table[a * 26 + b];
+  PSA_HIP(hipSetDevice(c->device));
+  PSA_HIP(hipMemcpy(c->d_table_t, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->have_table = true;
+  return PSA_OK;
+}
+
+int psa_set_weights(psa_ctx *c, const float weights[4]) {
+  if (!c || !weights) return PSA_ERR_ARG;
+  float t[PSA_TABLE_SIZE];
+  psa::build_table_from_weights(weights, t);
+  return psa_set_table(c, t);
+}
+
+void psa_batch_destroy(psa_batch *b) {
+  if (!b) return;
+  if (b->ctx) (void)hipSetDevice(b->ctx->device);
+  if (b->d_pool) (void)hipFree(b->d_pool);
+  if (b->d_desc) (void)hipFree(b->d_desc);
+  if (b->d_acc) (void)hipFree(b->d_acc);
+  if (b->d_counters) (void)hipFree(b->d_counters);
+  for (int c = 0; c < psa::kEnumClasses; ++c) {
+    if (b->d_chunks[c]) (void)hipFree(b->d_chunks[c]);
+    if (b->ev_b[c]) (void)hipEventDestroy(b->ev_b[c]);
+    if (b->ev_e[c]) (void)hipEventDestroy(b->ev_e[c]);
+  }
+  if (b->d_fwd) (void)hipFree(b->d_fwd);
+  if (b->d_fs) (void)hipFree(b->d_fs);
+  if (b->d_active) (void)hipFree(b->d_active);
+  if (b->d_out) (void)hipFree(b->d_out);
+  if (b->h_out) (void)hipHostFree(b->h_out);
+  for (hipEvent_t e : {b->ev_first, b->ev_last, b->ev_init, b->ev_res})
+    if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, bool ranged, int64_t rb,
+                       int64_t re, psa_batch **out) {
+  if (!out) return PSA_ERR_ARG;
+  *out = nullptr;
+  if (!c || n < 0 || (n > 0 && !seq2)) return PSA_ERR_ARG;
+  if (!c->have_seq1 || !c->have_table) return PSA_ERR_STATE;
+  PSA_HIP(hipSetDevice(c->device));
+  psa_batch *b = new (std::nothrow) psa_batch();
+  if (!b) return PSA_ERR_NOMEM;
+  b->ctx = c;
+  b->n = n;
+  b->desc.resize((size_t)n);
+  b->tmpl.assign((size_t)n, psa_result{});
+  std::vector<unsigned char> pool;
+  std::vector<psa::Chunk> chunks[psa::kEnumClasses];
+  std::vector<psa::FwdBlock> fwd;
+  int64_t class_offsets[psa::kEnumClasses] = {};
+  int64_t fs_total = 0;
+
+  for (int i = 0; i < n; ++i) {
+    psa::SeqDesc &d = b->desc[(size_t)i];
+    psa_result &r = b->tmpl[(size_t)i];
+    d = psa::SeqDesc{};
+    d.frac_bits = -1;
+    r.enum_frac_bits = -1;
+    r.enum_exact = -1;
+    const char *s2 = seq2[i];
+    if (!s2) {
+      r.status = PSA_ERR_ARG;
+      continue;
+    }
+    int64_t L2 = len2 ? len2[i] : (int64_t)std::strlen(s2);
+    if (L2 < 2) {
+      r.status = PSA_ERR_SEQ2_SHORT;
+      continue;
+    }
+    if (L2 - 2 > c->len1 || L2 > PSA_MAX_SEQ2) {
+      r.status = PSA_ERR_SEQ2_LONG;
+      continue;
+    }
+    bool ok = true;
+    for (int64_t j = 0; j < L2 && ok; ++j) ok = s2[j] >= 'A' && s2[j] <= 'Z';
+    if (!ok) {
+      r.status = PSA_ERR_RESIDUE;
+      continue;
+    }
+    const int64_t S = c->len1 - L2 + 3;
+    int64_t sb = 0, se = S;
+    if (ranged) {
+      sb = std::max<int64_t>(rb, 0);
+      se = std::min<int64_t>(re, S);
+      if (se <= sb) {
+        r.status = PSA_ERR_ARG;
+        continue;
+      }
+    }
+    d.off2 = (int32_t)pool.size();
+    for (int64_t j = 0; j < L2; ++j) pool.push_back((unsigned char)(s2[j] - 'A'));
+    while (pool.size() % 16) pool.push_back((unsigned char)psa::kPadCode);
+    d.len2 = (int32_t)L2;
+    d.s_begin = (int32_t)sb;
+    d.s_end = (int32_t)se;
+    d.fs_base = fs_total;
+    fs_total += se - sb;
+    int exact = -1;
+    d.frac_bits = psa::choose_frac_bits(c->table, L2, &exact);
+    if (psa::enum_class_of((int)L2) < 0) d.frac_bits = -1;
+    r.enum_frac_bits = d.frac_bits;
+    r.enum_exact = d.frac_bits >= 0 ? exact : -1;
+    r.candidates = (se - sb) * (L2 * (L2 - 1) / 2);
+    r.status = PSA_OK;
+    b->max_len2 = std::max<int>(b->max_len2, (int)L2);
+    b->nvalid++;
+    if (d.frac_bits >= 0) class_offsets[psa::enum_class_of((int)L2)] += se - sb;
+    for (int64_t s0 = sb; s0 < se; s0 += 256) fwd.push_back(psa::FwdBlock{i, (int32_t)s0});
+  }
+  b->total_offsets = fs_total;
+
+  // enumeration chunks: a few offsets each, longest Seq2 first so that the work
+  // counter hands out the expensive chunks early
+  std::vector<int> order;
+  for (int i = 0; i < n; ++i)
+    if (b->tmpl[(size_t)i].status == PSA_OK && b->desc[(size_t)i].frac_bits >= 0) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int x, int y) { return b->desc[(size_t)x].len2 > b->desc[(size_t)y].len2; });
+  int resident[psa::kEnumClasses];
+  for (int k = 0; k < psa::kEnumClasses; ++k) {
+    int per_cu = (int)std::min<size_t>(kLdsPerCu / (size_t)psa::enum_class_lds_bytes(k),
+                                       (size_t)(2048 / psa::enum_class_threads(k)));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    resident[k] = per_cu * c->num_cus;
+  }
+  for (int i : order) {
+    const psa::SeqDesc &d = b->desc[(size_t)i];
+    const int k = psa::enum_class_of(d.len2);
+    int64_t ns = class_offsets[k] / ((int64_t)resident[k] * 8);
+    ns = std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
+    for (int64_t s0 = d.s_begin; s0 < d.s_end; s0 += ns)
+      chunks[k].push_back(psa::Chunk{i, (int32_t)s0, (int32_t)std::min<int64_t>(ns, d.s_end - s0), 0});
+  }
+
+  int st = PSA_OK;
+  auto fail = [&](int code) {
+    psa_batch_destroy(b);
+    return code;
+  };
+  if ((st = upload(&b->d_pool, pool)) != PSA_OK) return fail(st);
+  if ((st = upload(&b->d_desc, b->desc)) != PSA_OK) return fail(st);
+  if ((st = upload(&b->d_fwd, fwd)) != PSA_OK) return fail(st);
+  b->nfwd = (int)fwd.size();
+  for (int k = 0; k < psa::kEnumClasses; ++k) {
+    if ((st = upload(&b->d_chunks[k], chunks[k])) != PSA_OK) return fail(st);
+    b->nchunks[k] = (int)chunks[k].size();
+    b->grid[k] = std::min(b->nchunks[k], resident[k]);
+  }
+#define PSA_HIP_B(call)                                               \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) {                                           \
+      g_err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+      return fail(PSA_ERR_HIP);                                       \
+    }                                                                 \
+  } while (0)
+  if (n > 0) {
+    PSA_HIP_B(hipMalloc((void **)&b->d_acc, (size_t)n * sizeof(psa::SeqAcc)));
+    PSA_HIP_B(hipMalloc((void **)&b->d_out, (size_t)n * sizeof(psa_result)));
+    PSA_HIP_B(hipHostMalloc((void **)&b->h_out, (size_t)n * sizeof(psa_result), hipHostMallocDefault));
+    PSA_HIP_B(hipMemcpy(b->d_out, b->tmpl.data(), (size_t)n * sizeof(psa_result), hipMemcpyHostToDevice));
+    std::memcpy(b->h_out, b->tmpl.data(), (size_t)n * sizeof(psa_result));
+  }
+  PSA_HIP_B(hipMalloc((void **)&b->d_counters, (psa::kEnumClasses + 1) * sizeof(unsigned)));
+  if (fs_total > 0) {
+    PSA_HIP_B(hipMalloc((void **)&b->d_fs, (size_t)fs_total * sizeof(float)));
+    PSA_HIP_B(hipMalloc((void **)&b->d_active, (size_t)fs_total * sizeof(psa::ActiveOffset)));
+  }
+  for (hipEvent_t *e : {&b->ev_first, &b->ev_last, &b->ev_init, &b->ev_res}) PSA_HIP_B(hipEventCreate(e));
+  for (int k = 0; k < psa::kEnumClasses; ++k) {
+    PSA_HIP_B(hipEventCreate(&b->ev_b[k]));
+    PSA_HIP_B(hipEventCreate(&b->ev_e[k]));
+  }
+#undef PSA_HIP_B
+  *out = b;
+  return PSA_OK;
+}
+
+int psa_batch_create(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, psa_batch **out) {
+  return batch_build(c, n, seq2, len2, false, 0, 0, out);
+}
+
+int psa_batch_create_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end,
+                           psa_batch **out) {
+  const char *one[1] = {seq2};
+  int32_t l[1] = {len2};
+  return batch_build(c, 1, one, len2 >= 0 ? l : nullptr, true, s_begin, s_end, out);
+}
+
+int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
+
+int psa_batch_run(psa_batch *b, uint32_t stages) {
+  if (!b) return PSA_ERR_ARG;
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  psa_ctx *c = b->ctx;
+  b->last_stages = stages;
+  b->ran = false;
+  if (b->n == 0) {
+    b->ran = true;
+    return PSA_OK;
+  }
+  PSA_HIP(hipSetDevice(c->device));
+  PSA_HIP(hipEventRecord(b->ev_first, c->st_enum));
+  PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, psa::kEnumClasses + 1, c->st_enum));
+  PSA_HIP(hipEventRecord(b->ev_init, c->st_enum));
+  PSA_HIP(psa::debug_sync("psa_init_acc"));
+  bool timed[psa::kEnumClasses] = {};
+  if ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) {
+    PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
+    psa::ResolveParams P{};
+    P.seq1 = c->d_seq1;
+    P.len1 = c->len1;
+    P.seq2_pool = b->d_pool;
+    P.desc = b->d_desc;
+    P.fwd_blocks = b->d_fwd;
+    P.acc = b->d_acc;
+    P.table_t = c->d_table_t;
+    P.fs = b->d_fs;
+    P.active = b->d_active;
+    P.nactive = b->d_counters + psa::kEnumClasses;
+    P.pchunks = (b->max_len2 + 255) / 256;
+    int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
+    PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res));
+    PSA_HIP(hipEventRecord(b->ev_res, c->st_res));
+  }
+  if (stages & PSA_STAGE_ENUMERATE) {
+    for (int k = 0; k < psa::kEnumClasses; ++k) {
+      if (b->nchunks[k] == 0) continue;
+      psa::EnumParams P{};
+      P.seq1 = c->d_seq1;
+      P.len1 = c->len1;
+      P.seq2_pool = b->d_pool;
+      P.desc = b->d_desc;
+      P.chunks = b->d_chunks[k];
+      P.nchunks = b->nchunks[k];
+      P.counter = b->d_counters + k;
+      P.acc = b->d_acc;
+      P.table_t = c->d_table_t;
+      PSA_HIP(psa::launch_enum(k, P, b->grid[k], b->grid[k], c->st_enum, b->ev_b[k], b->ev_e[k]));
+      timed[k] = true;
+    }
+  }
+  if ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_res, 0));
+  psa::FinalParams F{};
+  F.seq1 = c->d_seq1;
+  F.seq2_pool = b->d_pool;
+  F.desc = b->d_desc;
+  F.acc = b->d_acc;
+  F.class_t = c->d_class_t;
+  F.out = b->d_out;
+  F.stages = stages;
+  PSA_HIP(psa::launch_finalize(F, b->n, c->st_enum));
+  PSA_HIP(psa::debug_sync("psa_finalize"));
+  PSA_HIP(hipMemcpyAsync(b->h_out, b->d_out, (size_t)b->n * sizeof(psa_result), hipMemcpyDeviceToHost, c->st_enum));
+  PSA_HIP(hipEventRecord(b->ev_last, c->st_enum));
+  PSA_HIP(hipStreamSynchronize(c->st_enum));
+  PSA_HIP(hipStreamSynchronize(c->st_res));
+  b->enum_ms = 0.f;
+  for (int k = 0; k < psa::kEnumClasses; ++k) {
+    if (!timed[k]) continue;
+    float ms = 0.f;
+    PSA_HIP(hipEventElapsedTime(&ms, b->ev_b[k], b->ev_e[k]));
+    b->enum_ms += ms;
+  }
+  PSA_HIP(hipEventElapsedTime(&b->total_ms, b->ev_first, b->ev_last));
+  b->ran = true;
+  return PSA_OK;
+}
+
+int psa_batch_results(const psa_batch *b, psa_result *out) {
+  if (!b || (!out && b->n > 0)) return PSA_ERR_ARG;
+  if (!b->ran) return PSA_ERR_STATE;
+  if (b->n > 0) std::memcpy(out, b->h_out, (size_t)b->n * sizeof(psa_result));
+  return PSA_OK;
+}
+
+int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms) {
+  if (!b || !b->ran) return PSA_ERR_STATE;
+  if (enum_kernel_ms) *enum_kernel_ms = b->enum_ms;
+  if (total_ms) *total_ms = b->total_ms;
+  return PSA_OK;
+}
+
+int psa_score_batch(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, uint32_t stages,
+                    psa_result *out) {
+  psa_batch *b = nullptr;
+  int st = psa_batch_create(c, n, seq2, len2, &b);
+  if (st != PSA_OK) return st;
+  st = psa_batch_run(b, stages);
+  if (st == PSA_OK) st = psa_batch_results(b, out);
+  psa_batch_destroy(b);
+  return st;
+}
+
+int psa_score_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end, uint32_t stages,
+                    psa_result *out) {
+  psa_batch *b = nullptr;
+  int st = psa_batch_create_range(c, seq2, len2, s_begin, s_end, &b);
+  if (st != PSA_OK) return st;
+  st = psa_batch_run(b, stages);
+  if (st == PSA_OK) st = psa_batch_results(b, out);
+  psa_batch_destroy(b);
+  return st;
+}
+
+// ---- drop-in for calc_best_score_CUDA (P/cudaFunctions.cu:260-323) ----------------
+// Keeps one context alive; Seq1 and the table are uploaded again only when they
+// change between calls (the reference re-uploads both for every Seq2 and never frees).
+char *psa_calc_best_score(const char *seq1, const char *seq2, const float *comp_matrix) {
+  static psa_ctx *ctx = nullptr;
+  static std::string cached_seq1;
+  static float cached_table[PSA_TABLE_SIZE];
+  static bool have_table = false;
+  auto die = [](const char *what, int st) {
+    std::fprintf(stderr, "%s: %s (%s)\n", what, psa_strerror(st), psa_last_error_text());
+    std::exit(EXIT_FAILURE);
+  };
+  if (!seq1 || !seq2 || !comp_matrix) die("psa_calc_best_score", PSA_ERR_ARG);
+  int st;
+  if (!ctx) {
+    const char *dev = std::getenv("PSA_DEVICE");
+    if ((st = psa_init(dev ? std::atoi(dev) : 0, &ctx)) != PSA_OK) die("psa_init", st);
+  }
+  if (cached_seq1 != seq1) {
+    if ((st = psa_set_seq1(ctx, seq1, -1)) != PSA_OK) die("psa_set_seq1", st);
+    cached_seq1 = seq1;
+  }
+  if (!have_table || std::memcmp(cached_table, comp_matrix, sizeof cached_table) != 0) {
+    if ((st = psa_set_table(ctx, comp_matrix)) != PSA_OK) die("psa_set_table", st);
+    std::memcpy(cached_table, comp_matrix, sizeof cached_table);
+    have_table = true;
+  }
+  psa_result r{};
+  const char *one[1] = {seq2};
+  // the reference's answer is the float32 one; the enumeration stage is not needed for it
+  if ((st = psa_score_batch(ctx, 1, one, nullptr, PSA_STAGE_RESOLVE, &r)) != PSA_OK) die("psa_score_batch", st);
+  if (r.status != PSA_OK) die("psa_calc_best_score", r.status);
+  char *line = psa_format_result(&r);
+  if (!line) die("psa_format_result", PSA_ERR_NOMEM);
+  const char *quiet = std::getenv("PSA_SHIM_QUIET");
+  if (!(quiet && quiet[0] == '1')) std::printf("%s", line);  // P/cudaFunctions.cu:321
+  return line;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// Host-side helpers of libpsa_hip: the residue-class table, the table builder,
+// mutant numbering, result formatting and the work split.  No GPU code here.
+// Citations: P/ = "Parallel Solution/", S/ = "Sequential Solution/".
+#include "psa_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace psa {
+
+// Group memberships as 26-bit masks (bit i = letter 'A'+i).  Two different
+// letters are conservative if some conservative group holds both, otherwise
+// semi-conservative if some semi-conservative group holds both
+// (P/cFunctions.c:84-100); identity is tested first (P/cFunctions.c:68).
+static uint32_t mask_of(const char *letters) {
+  uint32_t m = 0;
+  for (; *letters; ++letters) m |= 1u << (*letters - 'A');
+  return m;
+}
+
+struct ClassMasks {
+  uint32_t cons[26];
+  uint32_t semi[26];
+  ClassMasks() {
+    static const char *const kCons[] = {"NDEQ", "NEQK", "STA", "MILV", "QHRK", "NHQK", "FYW", "HY", "MILF"};
+    static const char *const kSemi[] = {"SAG",    "ATV",    "CSA",    "SGND", "STPA", "STNK",
+                                        "NEQHRK", "NDEQHK", "SNDEQK", "HFY",  "FVLIM"};
+    std::memset(cons, 0, sizeof cons);
+    std::memset(semi, 0, sizeof semi);
+    for (const char *g : kCons) {
+      uint32_t m = mask_of(g);
+      for (int a = 0; a < 26; ++a)
+        if (m >> a & 1) cons[a] |= m;
+    }
+    for (const char *g : kSemi) {
+      uint32_t m = mask_of(g);
+      for (int a = 0; a < 26; ++a)
+        if (m >> a & 1) semi[a] |= m;
+    }
+  }
+};
+
+int residue_class_code(int a, int b) {
+  static const ClassMasks masks;
+  if (a == b) return 0;
+  if (a < 0 || a > 25 || b < 0 || b > 25) return 3;
+  if (masks.cons[a] >> b & 1) return 1;
+  if (masks.semi[a] >> b & 1) return 2;
+  return 3;
+}
+
+void build_table_from_weights(const float w[4], float out[PSA_TABLE_SIZE]) {
+  for (int a = 0; a < 26; ++a)
+    for (int b = 0; b < 26; ++b) {
+      int c = residue_class_code(a, b);
+      out[a * 26 + b] = c == 0 ? w[0] : -w[c];
+    }
+}
+
+// Fixed-point scale of the enumeration stage: the largest r in [0,24] such that
+// len2 * max|round(entry * 2^r)| <= 2^29 - 1.  Then any prefix sum is below 2^29
+// in magnitude, the two halves f and g of a candidate score below 2^30, and
+// their sum inside int32.
+int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int *exact_level) {
+  const int64_t limit = (int64_t(1) << 29) - 1;
+  int r = 24;
+  for (; r >= 0; --r) {
+    int64_t mx = 0;
+    bool ok = true;
+    for (int i = 0; i < PSA_TABLE_SIZE && ok; ++i) {
+      double v = std::nearbyint(std::ldexp(double(table[i]), r));
+      if (!(std::fabs(v) < 4e18)) ok = false;
+      else mx = std::max<int64_t>(mx, std::llabs((long long)v));
+    }
+    if (ok && mx <= limit / std::max<int64_t>(len2, 1)) break;
+  }
+  if (r < 0) {
+    *exact_level = -1;
+    return -1;
+  }
+  // exactness: 1 if every entry is k * 2^-r, 2 if moreover all partial sums of up
+  // to len2 entries fit the 24-bit significand of float32 at the coarsest such scale
+  bool table_exact = true;
+  int64_t mx = 0;
+  int min_tz = 63;
+  for (int i = 0; i < PSA_TABLE_SIZE; ++i) {
+    double v = std::nearbyint(std::ldexp(double(table[i]), r));
+    if (std::ldexp(v, -r) != double(table[i])) table_exact = false;
+    int64_t iv = std::llabs((long long)v);
+    mx = std::max(mx, iv);
+    if (iv) min_tz = std::min(min_tz, __builtin_ctzll((unsigned long long)iv));
+  }
+  *exact_level = 0;
+  if (table_exact) {
+    *exact_level = 1;
+    int shift = mx == 0 ? 0 : std::min(min_tz, r);
+    if ((mx >> shift) * len2 < (int64_t(1) << 24)) *exact_level = 2;
+  }
+  return r;
+}
+
+// Row n of the mutant triangle starts at 1-based number (n-1)*L - n(n-1)/2 + 1.
+static inline int64_t row_start(int64_t n, int64_t L) { return (n - 1) * L - n * (n - 1) / 2 + 1; }
+
+void nk_of_mutant(int64_t t, int len2, int *n, int *k) {
+  const int64_t L = len2;
+  const int64_t M = L * (L - 1) / 2;
+  if (t < 1) t = 1;
+  if (t > M) {
+    // the reference's loop runs off the last row and reports n = len2 (P/cFunctions.c:108-118)
+    *n = len2;
+    *k = (int)(len2 + (t - M));
+    return;
+  }
+  // solve row_start(n) <= t by the quadratic formula, then fix the rounding
+  double disc = (2.0 * L - 1.0) * (2.0 * L - 1.0) - 8.0 * double(t - 1);
+  int64_t row = (int64_t)(((2.0 * L - 1.0) - std::sqrt(std::max(disc, 0.0))) / 2.0) + 1;
+  row = std::clamp<int64_t>(row, 1, L - 1);
+  while (row > 1 && row_start(row, L) > t) --row;
+  while (row < L - 1 && row_start(row + 1, L) <= t) ++row;
+  *n = (int)row;
+  *k = (int)(row + (t - row_start(row, L) + 1));
+}
+
+int64_t mutant_of_nk(int n, int k, int len2) { return row_start(n, len2) + (k - n) - 1; }
+
+// Longest-processing-time assignment on the candidate count of each Seq2.
+int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner) {
+  if (n < 0 || nparts < 1 || (n > 0 && (!len2 || !owner))) return PSA_ERR_ARG;
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::vector<double> cost(n);
+  for (int i = 0; i < n; ++i) {
+    double L2 = len2[i], S = double(len1) - L2 + 3.0;
+    cost[i] = S > 0 && L2 >= 2 ? S * L2 * (L2 - 1.0) * 0.5 : 0.0;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  std::vector<double> load(nparts, 0.0);
+  for (int idx : order) {
+    int best = 0;
+    for (int p = 1; p < nparts; ++p)
+      if (load[p] < load[best]) best = p;
+    owner[idx] = best;
+    load[best] += cost[idx];
+  }
+  return PSA_OK;
+}
+
+}  // namespace psa
+
+extern "C" {
+
+void psa_create_comp_matrix(float *arr, int size, const float *weights) {
+  if (!arr || !weights || size < PSA_TABLE_SIZE) return;
+  psa::build_table_from_weights(weights, arr);
+}
+
+int psa_residue_class(char a, char b) { return psa::residue_class_code(a - 'A', b - 'A'); }
+
+void psa_get_nk(int64_t mutant_number, int len2, int *n, int *k) {
+  int nn = 0, kk = 0;
+  psa::nk_of_mutant(mutant_number, len2, &nn, &kk);
+  if (n) *n = nn;
+  if (k) *k = kk;
+}
+
+int64_t psa_mutant_number(int n, int k, int len2) { return psa::mutant_of_nk(n, k, len2); }
+
+char *psa_format_result(const psa_result *r) {
+  if (!r) return nullptr;
+  char *line = nullptr;
+  // same conversion specifications as P/cFunctions.c:157 (its trailing "%c" of '\0' adds no visible byte)
+  if (asprintf(&line, "mutant num: %d, MS(%d,%d), score: %1.2f, offset: %d\n", r->mutant_num, r->n, r->k,
+               (double)r->score, r->offset) < 0)
+    return nullptr;
+  return line;
+}
+
+int psa_partition(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner) {
+  return psa::partition_by_cost(n, len2, len1, nparts, owner);
+}
+
+void psa_calc_portion(int *portion, int num) {
+  // P/cFunctions.c:49-52: floor(num/2) for the first worker, the rest for the second
+  if (!portion) return;
+  portion[0] = num / 2;
+  portion[1] = num - num / 2;
+}
+
+const char *psa_strerror(int status) {
+  switch (status) {
+    case PSA_OK: return "ok";
+    case PSA_ERR_ARG: return "invalid argument";
+    case PSA_ERR_SEQ2_SHORT: return "Seq2 shorter than 2 characters";
+    case PSA_ERR_SEQ2_LONG: return "Seq2 too long for Seq1 or for the kernels";
+    case PSA_ERR_RESIDUE: return "character outside 'A'..'Z'";
+    case PSA_ERR_HIP: return "HIP runtime error";
+    case PSA_ERR_NO_DEVICE: return "no usable GPU";
+    case PSA_ERR_STATE: return "Seq1 or table not set";
+    case PSA_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char *psa_version(void) { return "psa-hip 0.1 (gfx950)"; }
+
+int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
+  if (!parts || !out || nparts < 1) return PSA_ERR_ARG;
+  int bi = -1, be = -1;
+  int64_t cand = 0;
+  for (int i = 0; i < nparts; ++i) {
+    const psa_result &p = parts[i];
+    if (p.status != PSA_OK) {
+      *out = p;
+      return p.status;
+    }
+    cand += p.candidates;
+    if (p.n > 0) {
+      bool better = bi < 0 || p.score > parts[bi].score;
+      if (!better && p.score == parts[bi].score) {
+        const psa_result &q = parts[bi];
+        better = p.n < q.n || (p.n == q.n && (p.k < q.k || (p.k == q.k && p.offset < q.offset)));
+      }
+      if (better) bi = i;
+    }
+    if (p.enum_frac_bits >= 0 && p.enum_n > 0) {
+      bool better = be < 0 || p.enum_score > parts[be].enum_score;
+      if (!better && p.enum_score == parts[be].enum_score) {
+        const psa_result &q = parts[be];
+        better = p.enum_n < q.enum_n ||
+                 (p.enum_n == q.enum_n && (p.enum_k < q.enum_k || (p.enum_k == q.enum_k && p.enum_offset < q.enum_offset)));
+      }
+      if (better) be = i;
+    }
+  }
+  *out = parts[bi >= 0 ? bi : 0];
+  if (be >= 0) {
+    const psa_result &e = parts[be];
+    out->enum_n = e.enum_n;
+    out->enum_k = e.enum_k;
+    out->enum_offset = e.enum_offset;
+    out->enum_score = e.enum_score;
+    out->enum_frac_bits = e.enum_frac_bits;
+    out->enum_exact = e.enum_exact;
+    std::memcpy(out->enum_counts, e.enum_counts, sizeof e.enum_counts);
+  }
+  out->candidates = cand;
+  return PSA_OK;
+}
+
+}  // extern "C"

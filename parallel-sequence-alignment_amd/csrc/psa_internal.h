@@ -1,0 +1,67 @@
+// Internal declarations shared by the host helpers, the kernels and the C ABI.
+#ifndef PSA_INTERNAL_H
+#define PSA_INTERNAL_H
+
+#include <stdint.h>
+
+#include "../../include/psa.h"
+
+namespace psa {
+
+// Device tables are stored with a row stride of 32 and 27 rows: code 26 is the
+// padding residue (positions outside a sequence); its row and column are zero.
+// They are indexed [seq2 code][seq1 code] so that lanes which differ only in the
+// Seq1 residue read one 27-word row.
+constexpr int kRowStride = 32;
+constexpr int kPadCode = 26;
+constexpr int kDevTable = 27 * kRowStride;  // 864 entries
+
+// One Seq2 of a batch as the kernels see it.
+struct SeqDesc {
+  int64_t fs_base;    // index of this Seq2's first entry in the per-offset score array
+  int32_t off2;       // byte offset of its residue codes in the Seq2 pool
+  int32_t len2;
+  int32_t s_begin;    // offsets [s_begin, s_end) are scored
+  int32_t s_end;
+  int32_t frac_bits;  // fixed-point scale of the enumeration stage, -1 = stage off for this Seq2
+  int32_t pad;
+};
+
+// Per-Seq2 accumulators the kernels reduce into with 64/32-bit atomics.
+struct SeqAcc {
+  unsigned long long enum_key;  // max of (biased fixed-point score << 32 | ~p)
+  unsigned long long enum_loc;  // min of (q << 32 | offset) among candidates equal to the maximum with p = p*
+  unsigned long long res_loc;   // min of (q << 32 | offset) for the float32 path
+  uint32_t res_key;             // max of the order-preserving image of the float32 score
+  int32_t res_p;                // min p attaining the float32 maximum
+};
+
+// A unit of enumeration work: ns consecutive offsets of one Seq2.
+struct Chunk {
+  int32_t seq;
+  int32_t s0;
+  int32_t ns;
+  int32_t pad;
+};
+
+// A block of up to 256 consecutive offsets of one Seq2 for the forward recurrence.
+struct FwdBlock {
+  int32_t seq;
+  int32_t s0;
+};
+
+struct ActiveOffset {
+  int32_t seq;
+  int32_t s;
+};
+
+int residue_class_code(int a, int b);
+void build_table_from_weights(const float w[4], float out[PSA_TABLE_SIZE]);
+int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int *exact_level);
+void nk_of_mutant(int64_t t, int len2, int *n, int *k);
+int64_t mutant_of_nk(int n, int k, int len2);
+int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner);
+
+}  // namespace psa
+
+#endif

@@ -1,0 +1,311 @@
+"""Python host side of libpsa_hip (ctypes over the C ABI declared in include/psa.h).
+
+The names mirror the reference's host program ("Parallel Solution/main.c",
+"cFunctions.c"): readFromFile, createCompMatrix, calc_best_score (the drop-in for
+calc_best_score_CUDA), CPUGetNK, calcPortion, writeToFile.  Context and Batch
+wrap the resident-data API used by the benchmark and the multi-GPU drivers.
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible
+the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "libpsa_hip.so")
+
+PSA_TABLE_SIZE = 676
+STAGE_ENUMERATE = 1
+STAGE_RESOLVE = 2
+STAGE_BOTH = 3
+
+
+class PsaError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        txt = lib().psa_strerror(status).decode()
+        last = lib().psa_last_error_text().decode()
+        super().__init__("%s: %s%s" % (where or "libpsa_hip", txt, (" [" + last + "]") if last else ""))
+
+
+class Result(C.Structure):
+    """struct psa_result of include/psa.h"""
+    _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("offset", C.c_int32), ("mutant_num", C.c_int32),
+                ("score", C.c_float), ("score_bits", C.c_uint32), ("counts", C.c_int32 * 4),
+                ("enum_n", C.c_int32), ("enum_k", C.c_int32), ("enum_offset", C.c_int32),
+                ("enum_score", C.c_int32), ("enum_frac_bits", C.c_int32), ("enum_exact", C.c_int32),
+                ("enum_counts", C.c_int32 * 4), ("status", C.c_int32), ("reserved", C.c_int32),
+                ("candidates", C.c_int64)]
+
+    def key(self):
+        return (self.n, self.k, self.offset, self.score_bits)
+
+    def enum_key(self):
+        return (self.enum_n, self.enum_k, self.enum_offset, self.enum_score)
+
+    def as_dict(self):
+        d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("counts", "enum_counts", "reserved")}
+        d["counts"] = list(self.counts)
+        d["enum_counts"] = list(self.enum_counts)
+        return d
+
+
+_lib = None
+
+
+def lib():
+    """Loads libpsa_hip.so from the source tree; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libpsa_hip.so not built: run `make -C parallel-sequence-alignment_amd` "
+                      "(or __graft_entry__.build()) first; there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.psa_device_count.restype = C.c_int
+    L.psa_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.psa_shutdown.argtypes = [vp]
+    L.psa_shutdown.restype = None
+    L.psa_set_seq1.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.psa_set_weights.argtypes = [vp, f32p]
+    L.psa_set_table.argtypes = [vp, f32p]
+    L.psa_batch_create.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.POINTER(vp)]
+    L.psa_batch_create_range.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp)]
+    L.psa_batch_run.argtypes = [vp, C.c_uint32]
+    L.psa_batch_results.argtypes = [vp, C.POINTER(Result)]
+    L.psa_batch_timing.argtypes = [vp, f32p, f32p]
+    L.psa_batch_size.argtypes = [vp]
+    L.psa_batch_destroy.argtypes = [vp]
+    L.psa_batch_destroy.restype = None
+    L.psa_score_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.c_uint32, C.POINTER(Result)]
+    L.psa_score_range.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(Result)]
+    L.psa_combine_results.argtypes = [C.POINTER(Result), C.c_int, C.POINTER(Result)]
+    L.psa_calc_best_score.argtypes = [C.c_char_p, C.c_char_p, f32p]
+    L.psa_calc_best_score.restype = C.c_void_p  # malloc'd char*, freed below
+    L.psa_create_comp_matrix.argtypes = [f32p, C.c_int, f32p]
+    L.psa_create_comp_matrix.restype = None
+    L.psa_residue_class.argtypes = [C.c_char, C.c_char]
+    L.psa_get_nk.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.psa_get_nk.restype = None
+    L.psa_mutant_number.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.psa_mutant_number.restype = C.c_int64
+    L.psa_format_result.argtypes = [C.POINTER(Result)]
+    L.psa_format_result.restype = C.c_void_p
+    L.psa_partition.argtypes = [C.c_int, i32p, C.c_int64, C.c_int, i32p]
+    L.psa_calc_portion.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.psa_calc_portion.restype = None
+    L.psa_strerror.argtypes = [C.c_int]
+    L.psa_strerror.restype = C.c_char_p
+    L.psa_last_error_text.restype = C.c_char_p
+    L.psa_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _take_string(ptr):
+    if not ptr:
+        return None
+    s = C.string_at(ptr).decode()
+    _libc.free(ptr)
+    return s
+
+
+def _check(st, where):
+    if st != 0:
+        raise PsaError(st, where)
+
+
+def _bytes(s):
+    return s.encode() if isinstance(s, str) else bytes(s)
+
+
+# ---- the reference's host helpers ------------------------------------------------
+
+def readFromFile(file_name):
+    """Input grammar of P/cFunctions.c:17-37: four weights, Seq1, a count, then that
+    many Seq2, separated by whitespace; anything after them is ignored.
+    Returns (weights float32[4], seq1, [seq2...])."""
+    with open(file_name) as f:
+        tok = f.read().split()
+    weights = np.array([np.float32(t) for t in tok[0:4]], dtype=np.float32)
+    seq1 = tok[4]
+    count = int(tok[5])
+    return weights, seq1, tok[6:6 + count]
+
+
+def writeToFile(file, final_result):
+    """P/cFunctions.c:40-46"""
+    if file is None:
+        raise ValueError("writeToFile() - file is NULL")
+    file.write(final_result)
+
+
+def createCompMatrix(weights):
+    """26x26 float32 table of P/cFunctions.c:55-64, row = Seq1 residue."""
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    out = np.zeros(PSA_TABLE_SIZE, dtype=np.float32)
+    lib().psa_create_comp_matrix(out.ctypes.data_as(C.POINTER(C.c_float)), PSA_TABLE_SIZE,
+                                 w.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def residue_class(a, b):
+    return lib().psa_residue_class(_bytes(a)[:1], _bytes(b)[:1])
+
+
+def CPUGetNK(mutant_num, seq2_len):
+    """P/cFunctions.c:104-119: 1-based mutant number -> (n, k)."""
+    n, k = C.c_int(), C.c_int()
+    lib().psa_get_nk(mutant_num, seq2_len, C.byref(n), C.byref(k))
+    return n.value, k.value
+
+
+def mutant_number(n, k, seq2_len):
+    return lib().psa_mutant_number(n, k, seq2_len)
+
+
+def calcPortion(num):
+    """P/cFunctions.c:49-52"""
+    p = (C.c_int * 2)()
+    lib().psa_calc_portion(p, num)
+    return p[0], p[1]
+
+
+def partition(len2, len1, nparts):
+    """Cost-balanced owner of each Seq2 (replaces the count-based calcPortion)."""
+    l2 = np.ascontiguousarray(len2, dtype=np.int32)
+    owner = np.zeros(len(l2), dtype=np.int32)
+    _check(lib().psa_partition(len(l2), l2.ctypes.data_as(C.POINTER(C.c_int32)), len1, nparts,
+                               owner.ctypes.data_as(C.POINTER(C.c_int32))), "psa_partition")
+    return owner
+
+
+def calc_best_score(seq1, seq2, comp_matrix):
+    """Drop-in for calc_best_score_CUDA (P/cudaFunctions.cu:260): returns the result line."""
+    t = np.ascontiguousarray(comp_matrix, dtype=np.float32)
+    assert t.size == PSA_TABLE_SIZE
+    ptr = lib().psa_calc_best_score(_bytes(seq1), _bytes(seq2), t.ctypes.data_as(C.POINTER(C.c_float)))
+    return _take_string(ptr)
+
+
+def format_result(r):
+    return _take_string(lib().psa_format_result(C.byref(r)))
+
+
+def combine_results(parts):
+    arr = (Result * len(parts))(*parts)
+    out = Result()
+    _check(lib().psa_combine_results(arr, len(parts), C.byref(out)), "psa_combine_results")
+    return out
+
+
+# ---- resident-data API -------------------------------------------------------------
+
+class Context:
+    """One per GPU: Seq1 and the table stay in HBM across batches."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().psa_init(device, C.byref(self._h)), "psa_init")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().psa_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_seq1(self, seq1):
+        b = _bytes(seq1)
+        _check(lib().psa_set_seq1(self._h, b, len(b)), "psa_set_seq1")
+        self.len1 = len(b)
+
+    def set_weights(self, weights):
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        _check(lib().psa_set_weights(self._h, w.ctypes.data_as(C.POINTER(C.c_float))), "psa_set_weights")
+
+    def set_table(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        assert t.size == PSA_TABLE_SIZE
+        _check(lib().psa_set_table(self._h, t.ctypes.data_as(C.POINTER(C.c_float))), "psa_set_table")
+
+    def batch(self, seq2s):
+        return Batch(self, seq2s)
+
+    def batch_range(self, seq2, s_begin, s_end):
+        return Batch(self, [seq2], (s_begin, s_end))
+
+    def score_batch(self, seq2s, stages=STAGE_BOTH):
+        b = Batch(self, seq2s)
+        try:
+            return b.run(stages)
+        finally:
+            b.close()
+
+    def score_range(self, seq2, s_begin, s_end, stages=STAGE_BOTH):
+        b = Batch(self, [seq2], (s_begin, s_end))
+        try:
+            return b.run(stages)[0]
+        finally:
+            b.close()
+
+
+class Batch:
+    """A set of Seq2 resident in HBM with its work lists and result buffers."""
+
+    def __init__(self, ctx, seq2s, offset_range=None):
+        self._h = C.c_void_p()
+        self.ctx = ctx
+        bs = [_bytes(s) for s in seq2s]
+        self.n = len(bs)
+        if offset_range is None:
+            arr = (C.c_char_p * max(self.n, 1))(*bs)
+            lens = np.array([len(b) for b in bs], dtype=np.int32)
+            _check(lib().psa_batch_create(ctx._h, self.n, arr, lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          C.byref(self._h)), "psa_batch_create")
+        else:
+            assert self.n == 1
+            _check(lib().psa_batch_create_range(ctx._h, bs[0], len(bs[0]), offset_range[0], offset_range[1],
+                                                C.byref(self._h)), "psa_batch_create_range")
+
+    def launch(self, stages=STAGE_BOTH):
+        """Runs the kernels on the resident data and waits; no host copies of inputs."""
+        _check(lib().psa_batch_run(self._h, stages), "psa_batch_run")
+
+    def results(self):
+        out = (Result * max(self.n, 1))()
+        _check(lib().psa_batch_results(self._h, out), "psa_batch_results")
+        return list(out)[:self.n]
+
+    def run(self, stages=STAGE_BOTH):
+        self.launch(stages)
+        return self.results()
+
+    def timing(self):
+        """(enumeration kernel ms, first launch to last completion ms) of the last run"""
+        a, b = C.c_float(), C.c_float()
+        _check(lib().psa_batch_timing(self._h, C.byref(a), C.byref(b)), "psa_batch_timing")
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().psa_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,211 @@
+"""GPU parity: libpsa_hip (through its C ABI) against the CPU oracle and the golden
+vectors the compiled reference produced.  Bit-exact bar: n, k, offset and the
+float32 score bits; class counts; and for the enumeration stage the fixed-point
+score and its first maximiser."""
+import numpy as np
+import pytest
+
+from conftest import parse_weights, synth_problem, synth_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def psa():
+    import psa_amd
+    psa_amd.lib()
+    return psa_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(psa):
+    c = psa.Context(0)
+    yield c
+    c.close()
+
+
+def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=True):
+    for i, (seq2, r) in enumerate(zip(seq2s, results)):
+        assert r.status == 0, (i, r.status)
+        o = oracle.fast(seq1, seq2, table)
+        assert r.key() == o.as_tuple(), ("float path", i, seq2[:40], r.key(), o.as_tuple())
+        if expect is not None:
+            e = expect[i]
+            assert r.key() == (e["n"], e["k"], e["offset"], e["bits"]), ("golden", i)
+        assert r.mutant_num == o.mutant_num
+        assert tuple(r.counts) == oracle.counts(seq1, seq2, r.offset, r.n, r.k)
+        L2 = len(seq2)
+        assert r.candidates == (len(seq1) - L2 + 3) * (L2 * (L2 - 1) // 2)
+        if enum:
+            fr, itab, exact = oracle.fixed_table(table, L2)
+            assert r.enum_frac_bits == fr and r.enum_exact == exact
+            if fr >= 0:
+                e = oracle.enum_best(seq1, seq2, itab)
+                assert r.enum_key() == (e.n, e.k, e.offset, e.score), ("enum", i, seq2[:40], r.enum_key(),
+                                                                     (e.n, e.k, e.offset, e.score))
+                assert tuple(r.enum_counts) == oracle.counts(seq1, seq2, e.offset, e.n, e.k)
+                if exact == 2:
+                    assert (r.enum_n, r.enum_k, r.enum_offset) == (r.n, r.k, r.offset)
+                    assert r.enum_score == float(r.score) * 2.0 ** fr
+
+
+def test_golden_vectors(psa, ctx, oracle, golden):
+    total = 0
+    for case in golden:
+        w = parse_weights(case["weights"])
+        table = oracle.comp_matrix(w)
+        ctx.set_seq1(case["seq1"])
+        ctx.set_weights(w)
+        res = ctx.score_batch(case["seq2"])
+        check_against_oracle(oracle, case["seq1"], case["seq2"], table, res, expect=case["expected"])
+        total += len(res)
+    assert total >= 440
+
+
+def test_table_builder_matches_oracle(psa, oracle):
+    for w in ([2, 1.5, 1.1, 1.3], [1, 1, 1, 1], [0.1, 0.2, 0.3, 0.7]):
+        w = np.array(w, dtype=np.float32)
+        assert (psa.createCompMatrix(w) == oracle.comp_matrix(w)).all()
+
+
+def test_random_small_tie_heavy(psa, ctx, oracle):
+    rng = np.random.default_rng(123)
+    alphabets = ["AB", "NDEQ", "STAG", "HY", "ACDEFGHIKLMNPQRSTVWY", "A"]
+    weights = [(2, 1.5, 1.1, 1.3), (1, 1, 1, 1), (3, 0, 0, 0), (1.1, 1.1, 1.3, 1.3), (0.1, 0.2, 0.3, 0.7),
+               (1000.1, 0.3, 0.7, 0.001), (2, 1.5, 1, 1.25)]
+    for it in range(60):
+        alpha = alphabets[it % len(alphabets)]
+        w = np.array(weights[it % len(weights)], dtype=np.float32)
+        table = oracle.comp_matrix(w)
+        L1 = int(rng.integers(1, 90))
+        seq1 = synth_seq(rng, L1, alpha)
+        seq2s = [synth_seq(rng, int(rng.integers(2, min(L1 + 2, 40) + 1)), alpha) for _ in range(8)]
+        ctx.set_seq1(seq1)
+        ctx.set_weights(w)
+        check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+
+
+@pytest.mark.parametrize("L1,L2s", [(700, [130, 255, 256, 257, 300]), (1500, [511, 512, 513, 700]),
+                                    (2500, [1023, 1024, 1025, 1300]), (3000, [2000, 2047, 2048])])
+def test_register_class_boundaries(psa, ctx, oracle, L1, L2s):
+    """Seq2 lengths on both sides of every (threads x registers) kernel variant."""
+    seq1, seq2s = synth_problem(L1 + 1, L1, L2s)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+
+
+def test_config2_shape(psa, ctx, oracle):
+    """Seq1 = 3000, 4 x Seq2 = 2000 (the benchmark workload)."""
+    seq1, seq2s = synth_problem(2, 3000, [2000] * 4)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    b = ctx.batch(seq2s)
+    res = b.run()
+    check_against_oracle(oracle, seq1, seq2s, table, res)
+    again = b.run()  # same resident batch, second launch: identical records
+    assert [r.key() + r.enum_key() for r in again] == [r.key() + r.enum_key() for r in res]
+    em, tm = b.timing()
+    assert em > 0 and tm >= em
+    b.close()
+
+
+def test_exact_regime_weights(psa, ctx, oracle):
+    seq1, seq2s = synth_problem(5, 1200, [300, 301, 640])
+    for w in ([1, 1, 1, 1], [2, 1.5, 1, 1.25]):
+        w = np.array(w, dtype=np.float32)
+        table = oracle.comp_matrix(w)
+        ctx.set_seq1(seq1)
+        ctx.set_weights(w)
+        res = ctx.score_batch(seq2s)
+        assert all(r.enum_exact == 2 for r in res)
+        check_against_oracle(oracle, seq1, seq2s, table, res)
+
+
+def test_edge_stress(psa, ctx, oracle):
+    """L2 = L1-1, L2 = L1+2, period-2/3 repeats, all-same, tie-forcing weights."""
+    cases = []
+    for unit, L1 in (("AB", 300), ("ABC", 301), ("NDE", 257), ("A", 200), ("HYH", 130)):
+        seq1 = (unit * 400)[:L1]
+        cases.append((seq1, [(unit * 400)[1:L1], (unit * 400)[:L1 + 2], (unit[::-1] * 400)[:L1 - 3], seq1,
+                             (unit * 400)[:2], (unit * 400)[:3]]))
+    for w in ([1, 1, 1, 1], [2, 1.5, 1, 1.25], [1.1, 1.1, 1.3, 1.3], [0, 0, 0, 0]):
+        w = np.array(w, dtype=np.float32)
+        table = oracle.comp_matrix(w)
+        for seq1, seq2s in cases:
+            ctx.set_seq1(seq1)
+            ctx.set_weights(w)
+            check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+
+
+def test_arbitrary_float_table(psa, ctx, oracle):
+    rng = np.random.default_rng(9)
+    table = rng.normal(0, 3, size=676).astype(np.float32)
+    seq1, seq2s = synth_problem(8, 500, [40, 100, 260])
+    ctx.set_seq1(seq1)
+    ctx.set_table(table)
+    check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+
+
+def test_invalid_inputs(psa, ctx):
+    ctx.set_seq1("ABCDEFGH")
+    ctx.set_weights(np.array([2, 1.5, 1.1, 1.3], dtype=np.float32))
+    res = ctx.score_batch(["A", "ABCDEFGHIJK", "AB1D", "ABCD"])
+    assert [r.status for r in res] == [2, 3, 4, 0]
+    assert res[3].n >= 1
+    with pytest.raises(psa.PsaError):
+        ctx.set_seq1("abc")
+
+
+def test_offset_range_shards_combine(psa, ctx, oracle):
+    """Long-pair mode: shards of the offset range combine to the whole-range answer."""
+    seq1, seq2s = synth_problem(21, 5000, [600])
+    seq2 = seq2s[0]
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    whole = ctx.score_batch([seq2])[0]
+    S = len(seq1) - len(seq2) + 3
+    cuts = [0, S // 8, S // 3, S // 2 + 1, S]
+    parts = [ctx.score_range(seq2, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    for (a, b), p in zip(zip(cuts[:-1], cuts[1:]), parts):
+        o = oracle.fast(seq1, seq2, table, a, b)
+        assert p.key() == o.as_tuple()
+    comb = psa.combine_results(parts)
+    assert comb.key() == whole.key() and comb.enum_key() == whole.enum_key()
+    assert comb.candidates == whole.candidates
+    # all-equal scores: the tie must go to the smallest (n, k, offset), not to a shard
+    ctx.set_seq1("A" * 400)
+    parts = [ctx.score_range("A" * 50, a, b) for a, b in ((0, 100), (100, 250), (250, 353))]
+    comb = psa.combine_results(parts[::-1])
+    assert (comb.n, comb.k, comb.offset) == (1, 2, 0)
+
+
+def test_dropin_shim(psa, oracle, golden, capfd):
+    """psa_calc_best_score has calc_best_score_CUDA's contract: returns and echoes the line."""
+    case = [c for c in golden if c["name"] == "ref_s_input2.txt"][0]
+    table = psa.createCompMatrix(parse_weights(case["weights"]))
+    for seq2, e in zip(case["seq2"], case["expected"]):
+        line = psa.calc_best_score(case["seq1"], seq2, table)
+        score = np.array([e["bits"]], dtype=np.uint32).view(np.float32)[0]
+        mnum = psa.mutant_number(e["n"], e["k"], len(seq2)) - 1
+        assert line == "mutant num: %d, MS(%d,%d), score: %1.2f, offset: %d\n" % (mnum, e["n"], e["k"], score,
+                                                                                   e["offset"])
+
+
+def test_authors_recorded_output(psa):
+    """P/output.txt:1-4 -- what the CUDA program wrote for P/input.txt."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "inputs", "ref_input.txt")
+    w, seq1, seq2s = psa.readFromFile(path)
+    table = psa.createCompMatrix(w)
+    lines = [psa.calc_best_score(seq1, s, table) for s in seq2s]
+    assert lines == ["mutant num: 84, MS(1,86), score: 272.00, offset: 364\n",
+                     "mutant num: 176, MS(1,178), score: 2383.50, offset: 129\n",
+                     "mutant num: 207, MS(1,209), score: 343.30, offset: 858\n",
+                     "mutant num: 208, MS(1,210), score: 750.00, offset: 976\n"]

@@ -1,0 +1,88 @@
+"""CPU-only checks of libpsa_hip: the library loads, exports every symbol that
+include/psa.h declares, and its host-side helpers (no GPU work) agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def psa():
+    import psa_amd
+    psa_amd.lib()
+    return psa_amd
+
+
+def test_exports_every_declared_symbol(psa):
+    hdr = open(os.path.join(ROOT, "include", "psa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(psa_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    L = psa.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), n
+
+
+def test_result_struct_layout(psa):
+    assert C.sizeof(psa.Result) == 96
+
+
+def test_host_helpers_match_oracle(psa, oracle):
+    for a in range(26):
+        for b in range(26):
+            assert psa.residue_class(chr(65 + a), chr(65 + b)) == oracle.lib().psa_oracle_class(65 + a, 65 + b)
+    for w in ([2, 1.5, 1.1, 1.3], [2.5, 1.5, 1.1, 1.3], [0, 0, 0, 0]):
+        w = np.array(w, dtype=np.float32)
+        assert (psa.createCompMatrix(w).view(np.uint32) == oracle.comp_matrix(w).view(np.uint32)).all()
+    for L2 in (2, 3, 5, 64, 138, 2000, 8000):
+        M = L2 * (L2 - 1) // 2
+        for t in sorted(set([1, 2, L2 - 1, L2, L2 + 1, M // 2, M - 1, M]) & set(range(1, M + 1))):
+            assert psa.CPUGetNK(t, L2) == oracle.get_nk(t, L2)
+            n, k = psa.CPUGetNK(t, L2)
+            assert psa.mutant_number(n, k, L2) == t
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        L2 = int(rng.integers(2, 8192))
+        t = int(rng.integers(1, L2 * (L2 - 1) // 2 + 1))
+        assert psa.CPUGetNK(t, L2) == oracle.get_nk(t, L2)
+
+
+def test_format_and_portion(psa):
+    r = psa.Result()
+    r.mutant_num, r.n, r.k, r.offset, r.score = 84, 1, 86, 364, 272.0
+    assert psa.format_result(r) == "mutant num: 84, MS(1,86), score: 272.00, offset: 364\n"
+    assert psa.calcPortion(7) == (3, 4) and psa.calcPortion(4) == (2, 2)
+
+
+def test_partition_balances_cost(psa):
+    rng = np.random.default_rng(1)
+    len2 = rng.integers(500, 2001, size=4096).astype(np.int32)
+    L1 = 10000
+    for parts in (1, 2, 4, 8):
+        owner = psa.partition(len2, L1, parts)
+        cost = (L1 - len2 + 3).astype(np.float64) * len2 * (len2 - 1) / 2
+        loads = np.array([cost[owner == p].sum() for p in range(parts)])
+        assert loads.min() > 0 and loads.max() / loads.mean() < 1.01
+
+
+def test_combine_results_tie_order(psa):
+    def rec(score, n, k, off, cand=10):
+        r = psa.Result()
+        r.score, r.n, r.k, r.offset, r.candidates = score, n, k, off, cand
+        r.enum_frac_bits, r.enum_n, r.enum_k, r.enum_offset, r.enum_score = 3, n, k, off, int(score * 8)
+        return r
+    out = psa.combine_results([rec(5.0, 3, 4, 9), rec(7.5, 2, 9, 100), rec(7.5, 2, 9, 40), rec(7.5, 2, 10, 1)])
+    assert (out.n, out.k, out.offset, out.score) == (2, 9, 40, 7.5)
+    assert (out.enum_n, out.enum_k, out.enum_offset) == (2, 9, 40) and out.candidates == 40
+
+
+def test_no_gpu_means_loud_failure(psa):
+    """Without a GPU the product path must raise, never fall back to CPU code."""
+    if psa.lib().psa_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(psa.PsaError):
+        psa.Context(0)
