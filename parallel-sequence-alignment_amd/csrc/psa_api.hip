@@ -25,6 +25,7 @@ thread_local std::string g_err;
   } while (0)
 
 constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kResolveHeadroom = 40 * 1024;
 
 template <class T>
 int upload(T **dptr, const std::vector<T> &h) {
@@ -62,6 +63,7 @@ struct psa_batch {
   psa::SeqAcc *d_acc = nullptr;
   unsigned *d_counters = nullptr;  // kEnumClasses work counters + the active-offset count
   psa::Chunk *d_chunks[psa::kEnumClasses] = {};
+  unsigned long long *d_chunk_best[psa::kEnumClasses] = {};
   int nchunks[psa::kEnumClasses] = {};
   int grid[psa::kEnumClasses] = {};
   psa::FwdBlock *d_fwd = nullptr;
@@ -103,8 +105,12 @@ int psa_init(int device, psa_ctx **out) {
   hipDeviceProp_t prop;
   PSA_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  PSA_HIP(hipStreamCreateWithFlags(&c->st_enum, hipStreamNonBlocking));
-  PSA_HIP(hipStreamCreateWithFlags(&c->st_res, hipStreamNonBlocking));
+  // The resolve kernels are short and latency-bound; they run beside the long
+  // enumeration kernel on a stream of higher priority so their blocks are placed first.
+  int prio_low = 0, prio_high = 0;
+  PSA_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  PSA_HIP(hipStreamCreateWithPriority(&c->st_enum, hipStreamNonBlocking, prio_low));
+  PSA_HIP(hipStreamCreateWithPriority(&c->st_res, hipStreamNonBlocking, prio_high));
   PSA_HIP(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
   std::vector<unsigned char> cls(psa::kDevTable, 3);
@@ -177,6 +183,7 @@ void psa_batch_destroy(psa_batch *b) {
   if (b->d_counters) (void)hipFree(b->d_counters);
   for (int c = 0; c < psa::kEnumClasses; ++c) {
     if (b->d_chunks[c]) (void)hipFree(b->d_chunks[c]);
+    if (b->d_chunk_best[c]) (void)hipFree(b->d_chunk_best[c]);
     if (b->ev_b[c]) (void)hipEventDestroy(b->ev_b[c]);
     if (b->ev_e[c]) (void)hipEventDestroy(b->ev_e[c]);
   }
@@ -277,7 +284,12 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
                    [&](int x, int y) { return b->desc[(size_t)x].len2 > b->desc[(size_t)y].len2; });
   int resident[psa::kEnumClasses];
   for (int k = 0; k < psa::kEnumClasses; ++k) {
-    int per_cu = (int)std::min<size_t>(kLdsPerCu / (size_t)psa::enum_class_lds_bytes(k),
+    // leave kResolveHeadroom bytes of LDS per CU free so that blocks of the resolve
+    // kernels can be placed while the persistent enumeration blocks are resident
+    // (only where at least three enumeration blocks per CU remain)
+    const size_t lds = (size_t)psa::enum_class_lds_bytes(k);
+    const size_t with_room = (kLdsPerCu - kResolveHeadroom) / lds;
+    int per_cu = (int)std::min<size_t>(with_room >= 3 ? with_room : kLdsPerCu / lds,
                                        (size_t)(2048 / psa::enum_class_threads(k)));
     per_cu = std::max(1, std::min(per_cu, 8));
     resident[k] = per_cu * c->num_cus;
@@ -302,6 +314,11 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   b->nfwd = (int)fwd.size();
   for (int k = 0; k < psa::kEnumClasses; ++k) {
     if ((st = upload(&b->d_chunks[k], chunks[k])) != PSA_OK) return fail(st);
+    if (!chunks[k].empty() &&
+        hipMalloc((void **)&b->d_chunk_best[k], chunks[k].size() * sizeof(unsigned long long)) != hipSuccess) {
+      g_err = "hipMalloc(chunk_best) failed";
+      return fail(PSA_ERR_HIP);
+    }
     b->nchunks[k] = (int)chunks[k].size();
     b->grid[k] = std::min(b->nchunks[k], resident[k]);
   }
@@ -391,6 +408,7 @@ int psa_batch_run(psa_batch *b, uint32_t stages) {
       P.seq2_pool = b->d_pool;
       P.desc = b->d_desc;
       P.chunks = b->d_chunks[k];
+      P.chunk_best = b->d_chunk_best[k];
       P.nchunks = b->nchunks[k];
       P.counter = b->d_counters + k;
       P.acc = b->d_acc;

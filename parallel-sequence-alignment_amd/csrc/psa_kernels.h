@@ -21,6 +21,7 @@ struct EnumParams {
   unsigned *counter;               // work counter of this class (zeroed by psa_init_acc)
   SeqAcc *acc;
   const float *table_t;            // float table [seq2 code][seq1 code], stride 32, 27 rows
+  unsigned long long *chunk_best;  // per chunk: its (maximum, smallest p) key, written by psa_enum_main
 };
 
 struct ResolveParams {

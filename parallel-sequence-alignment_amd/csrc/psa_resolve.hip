@@ -1,0 +1,489 @@
+// gfx950 float32-exact resolve kernels of libpsa_hip, plus accumulator set-up and the
+// result records.
+//
+// The reference adds the table entries of a candidate left to right in float32
+// (P/cudaFunctions.cu:210-220, S/main.c:53-61).  Rounding to nearest is monotone
+// (x <= y implies fl(x+d) <= fl(y+d)), so the maximum over all (n,k) for one offset
+// follows from a three-state max-plus recurrence over Seq2 positions (psa_fwd), and
+// the first maximiser in (n, k, offset) order -- the reference's strict '>' rule
+// (S/main.c:74, P/cudaFunctions.cu:241, P/cFunctions.c:129,146) -- from two further
+// passes over the offsets that attain the maximum (psa_first_p, psa_first_q).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "psa_device.h"
+
+namespace psa {
+
+// ---------------------------------------------------------------------------------
+// per-batch initialisation of the accumulators and counters
+// ---------------------------------------------------------------------------------
+__global__ void psa_init_acc(SeqAcc *acc, int n, unsigned *counters, int ncounters) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    SeqAcc a;
+    a.enum_key = 0ull;
+    a.enum_loc = ~0ull;
+    a.res_loc = ~0ull;
+    a.res_key = 0u;
+    a.res_p = INT_MAX;
+    acc[i] = a;
+  }
+  if (i < ncounters) counters[i] = 0u;
+}
+
+// ---------------------------------------------------------------------------------
+// float32 resolve, pass 1: per-offset maximum over all (n,k); lanes = offsets.
+// State before Seq2 position j: a (no deletion yet), b (one), c (two).
+//   a' = a + T[A[s+j]][B[j]]
+//   b' = max(a, b + T[A[s+j-1]][B[j]])      delete j, or keep it after one deletion
+//   c' = max(b, c + T[A[s+j-2]][B[j]])
+// Rounding is monotone, so taking the max before continuing the chain is exact.
+//
+// LDS: table | Seq2 codes packed 4 per word | Seq1 window as byte offsets (4 * code)
+// Steps run in groups of four.  The twelve table entries of group g+1 are fetched
+// while the chain of group g is computed; Seq1 offsets and the Seq2 word are
+// fetched two groups ahead, so no LDS latency sits on the dependent chain.
+// ---------------------------------------------------------------------------------
+__host__ __device__ inline int fwd_bwords(int len2) { return (len2 + 3) / 4 + 4; }
+__host__ __device__ inline int fwd_window(int len2) { return 258 + len2 + 12; }
+
+__global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  FwdBlock fb;
+  fb.seq = uni(P.fwd_blocks[blockIdx.x].seq);
+  fb.s0 = uni(P.fwd_blocks[blockIdx.x].s0);
+  const SeqDesc d = load_desc(P.desc + fb.seq);
+  const int L2 = d.len2;
+  const char *Tb = (const char *)smem;                          // kDevTable floats
+  uint32_t *bw = (uint32_t *)(smem + kDevTable * 4);            // fwd_bwords(L2) words
+  int *aw = (int *)(bw + fwd_bwords(L2));                       // fwd_window(L2) byte offsets
+  uint32_t *red = (uint32_t *)(aw + fwd_window(L2));
+  for (int i = tid; i < kDevTable; i += 256) ((float *)smem)[i] = P.table_t[i];
+  {
+    const uint32_t *src = (const uint32_t *)(P.seq2_pool + d.off2);  // 16-byte aligned, padded to 16
+    const int nsrc = (L2 + 3) / 4;
+    for (int i = tid; i < fwd_bwords(L2); i += 256) bw[i] = i < nsrc ? src[i] : 0u;
+  }
+  const int win0 = fb.s0 - 2;
+  for (int i = tid; i < fwd_window(L2); i += 256) {
+    int64_t idx = (int64_t)win0 + i;
+    aw[i] = 4 * ((idx >= 0 && idx < P.len1) ? (int)P.seq1[idx] : kPadCode);
+  }
+  __syncthreads();
+  const int s = fb.s0 + tid;
+  const float NEG = -INFINITY;
+  float a = 0.0f, b = NEG, c = NEG;
+  int a2 = aw[tid], a1 = aw[tid + 1];
+  const int *ap = aw + tid + 2;  // ap[j] = 4 * code of Seq1[s + j]
+#define PSA_T(rowbytes, off) (*(const float *)(Tb + (rowbytes) + (off)))
+  // groups of four steps in which all three states advance: j + 3 <= L2 - 3
+  const int ngroups = (L2 - 2) / 4;
+  int4 o_cur, o_nxt;       // Seq1 offsets of the current / next group
+  uint32_t w_nxt, w_nxt2;  // Seq2 words of the next group / the one after
+  float x_cur[12], x_nxt[12];
+  o_cur = make_int4(ap[0], ap[1], ap[2], ap[3]);
+  o_nxt = make_int4(ap[4], ap[5], ap[6], ap[7]);
+  w_nxt = bw[1];
+  w_nxt2 = bw[2];
+  {
+    const uint32_t w0 = uni(bw[0]);
+    const int r0 = (w0 & 255) * 128, r1 = ((w0 >> 8) & 255) * 128, r2 = ((w0 >> 16) & 255) * 128,
+              r3 = (w0 >> 24) * 128;
+    x_cur[0] = PSA_T(r0, o_cur.x); x_cur[1] = PSA_T(r0, a1); x_cur[2] = PSA_T(r0, a2);
+    x_cur[3] = PSA_T(r1, o_cur.y); x_cur[4] = PSA_T(r1, o_cur.x); x_cur[5] = PSA_T(r1, a1);
+    x_cur[6] = PSA_T(r2, o_cur.z); x_cur[7] = PSA_T(r2, o_cur.y); x_cur[8] = PSA_T(r2, o_cur.x);
+    x_cur[9] = PSA_T(r3, o_cur.w); x_cur[10] = PSA_T(r3, o_cur.z); x_cur[11] = PSA_T(r3, o_cur.y);
+  }
+  for (int g = 0; g < ngroups; ++g) {
+    // fetch for group g+1 (its offsets and word arrived during the previous iteration)
+    const uint32_t wn = uni(w_nxt);
+    const int r0 = (wn & 255) * 128, r1 = ((wn >> 8) & 255) * 128, r2 = ((wn >> 16) & 255) * 128,
+              r3 = (wn >> 24) * 128;
+    x_nxt[0] = PSA_T(r0, o_nxt.x); x_nxt[1] = PSA_T(r0, o_cur.w); x_nxt[2] = PSA_T(r0, o_cur.z);
+    x_nxt[3] = PSA_T(r1, o_nxt.y); x_nxt[4] = PSA_T(r1, o_nxt.x); x_nxt[5] = PSA_T(r1, o_cur.w);
+    x_nxt[6] = PSA_T(r2, o_nxt.z); x_nxt[7] = PSA_T(r2, o_nxt.y); x_nxt[8] = PSA_T(r2, o_nxt.x);
+    x_nxt[9] = PSA_T(r3, o_nxt.w); x_nxt[10] = PSA_T(r3, o_nxt.z); x_nxt[11] = PSA_T(r3, o_nxt.y);
+    // fetch two groups ahead
+    const int jn = 4 * g + 8;
+    const int4 o_nn = make_int4(ap[jn], ap[jn + 1], ap[jn + 2], ap[jn + 3]);
+    const uint32_t w_nn = bw[g + 3];
+    // chain of group g
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float nc = fmaxf(b, c + x_cur[3 * k + 2]);
+      const float nb = fmaxf(a, b + x_cur[3 * k + 1]);
+      a = a + x_cur[3 * k];
+      b = nb;
+      c = nc;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) x_cur[k] = x_nxt[k];
+    a2 = o_cur.z;
+    a1 = o_cur.w;
+    o_cur = o_nxt;
+    o_nxt = o_nn;
+    w_nxt = w_nxt2;
+    w_nxt2 = w_nn;
+  }
+  // remaining positions, one at a time
+  const unsigned char *bcode = (const unsigned char *)bw;
+  for (int j = 4 * ngroups; j < L2; ++j) {
+    const int a0 = ap[j];
+    const int row = (int)bcode[j] * 128;
+    const float x0 = PSA_T(row, a0), x1 = PSA_T(row, a1), x2 = PSA_T(row, a2);
+    const float nc = fmaxf(b, c + x2);
+    const float nb = (j <= L2 - 2) ? fmaxf(a, b + x1) : NEG;  // one deletion must still follow
+    if (j <= L2 - 3) a = a + x0;                              // two deletions must still follow
+    b = nb;
+    c = nc;
+    a2 = a1;
+    a1 = a0;
+  }
+#undef PSA_T
+  uint32_t key = 0u;
+  if (s < d.s_end) {
+    P.fs[d.fs_base + (s - d.s_begin)] = c;
+    key = f2key(c);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    uint32_t o = __shfl_xor(key, m);
+    key = o > key ? o : key;
+  }
+  if (lane == 0) red[w] = key;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 4; ++i) key = red[i] > key ? red[i] : key;
+    atomicMax(&P.acc[fb.seq].res_key, key);
+  }
+}
+
+// pass 2: list the offsets whose maximum equals the Seq2's maximum
+__global__ __launch_bounds__(256) void psa_collect(ResolveParams P) {
+  const FwdBlock fb = P.fwd_blocks[blockIdx.x];
+  const SeqDesc d = P.desc[fb.seq];
+  const int s = fb.s0 + threadIdx.x;
+  if (s < d.s_end) {
+    const float v = P.fs[d.fs_base + (s - d.s_begin)];
+    if (f2key(v) == P.acc[fb.seq].res_key) {
+      unsigned idx = atomicAdd(P.nactive, 1u);
+      ActiveOffset ao;
+      ao.seq = fb.seq;
+      ao.s = s;
+      P.active[idx] = ao;
+    }
+  }
+}
+
+// Table entries seen by Seq2 position j at offset s after 0, 1, 2 deletions.
+// ---------------------------------------------------------------------------------
+// passes 3 and 4 work on one offset that attains the maximum.  LDS holds the table
+// entries Seq2 position j meets there after 0 deletions (d0[j]) and after 1 and 2
+// deletions (d12[j] = {d1, d2}).  d12[L2-1].x is -inf: a chain with one deletion
+// cannot consume the last position.  d12 is padded with 256 + 8 zero pairs so that
+// lanes may run past the end: adding +0.0 changes nothing.
+// ---------------------------------------------------------------------------------
+__host__ __device__ inline int tie_d0_len(int len2) { return ((len2 + 8 + 3) / 4) * 4; }
+__host__ __device__ inline int tie_d12_len(int len2) { return len2 + 256 + 8; }
+
+__device__ __forceinline__ void fill_diagonals(float *d0, float2 *d12, const float *T, const ResolveParams &P,
+                                               const SeqDesc &d, int s) {
+  const int L2 = d.len2;
+  for (int j = threadIdx.x; j < tie_d12_len(L2); j += blockDim.x) {
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+    if (j < L2) {
+      const int b = P.seq2_pool[d.off2 + j];
+      const float *row = T + b * kRowStride;
+      const int64_t i0 = (int64_t)s + j;
+      const int c0 = (i0 < P.len1) ? P.seq1[i0] : kPadCode;
+      const int c1 = (i0 - 1 >= 0 && i0 - 1 < P.len1) ? P.seq1[i0 - 1] : kPadCode;
+      const int c2 = (i0 - 2 >= 0 && i0 - 2 < P.len1) ? P.seq1[i0 - 2] : kPadCode;
+      v0 = row[c0];
+      v1 = (j == L2 - 1) ? -INFINITY : row[c1];
+      v2 = row[c2];
+    }
+    if (j < tie_d0_len(L2)) d0[j] = v0;
+    d12[j] = make_float2(v1, v2);
+  }
+}
+
+// v += d0[from .. to), left to right (every lane computes the same value)
+__device__ __forceinline__ float add_run_d0(const float *d0, int from, int to, float v) {
+  int j = from;
+  for (; j < to && (j & 3); ++j) v += d0[j];
+  for (; j + 4 <= to; j += 4) {
+    const float4 x = *(const float4 *)(d0 + j);
+    v += x.x;
+    v += x.y;
+    v += x.z;
+    v += x.w;
+  }
+  for (; j < to; ++j) v += d0[j];
+  return v;
+}
+
+// pass 3: lane p computes max_q score(s,p,q) exactly: the chain that deleted p starts
+// from a_p (the undeleted prefix sum) and then runs the same monotone recurrence,
+//   c' = max(v, c + d2[j]),  v' = v + d1[j]   for j = p+1 .. L2-1.
+// Lanes are skewed in time (lane p reads position p + t at step t), so every lane is in
+// the same phase and no per-lane selects are needed.  The smallest p that attains the
+// maximum wins.
+__global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
+  __shared__ int skip_flag[1];
+  float *T = (float *)smem;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kDevTable; i += 256) T[i] = P.table_t[i];
+  const unsigned nact = *P.nactive;
+  const long long nitems = (long long)nact * P.pchunks;
+  for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+    ActiveOffset ao;
+    ao.seq = uni(P.active[item / P.pchunks].seq);
+    ao.s = uni(P.active[item / P.pchunks].s);
+    const int pc = (int)(item % P.pchunks);
+    const SeqDesc d = load_desc(P.desc + ao.seq);
+    const int L2 = d.len2;
+    const int p0 = pc * 256;
+    if (p0 > L2 - 2) continue;
+    __syncthreads();
+    if (tid == 0) skip_flag[0] = p0 > P.acc[ao.seq].res_p;  // a smaller p is already known
+    __syncthreads();
+    if (uni(skip_flag[0])) continue;  // one decision for the whole block
+    float *d0 = T + kDevTable;
+    float2 *d12 = (float2 *)(d0 + tie_d0_len(L2));
+    fill_diagonals(d0, d12, T, P, d, ao.s);
+    __syncthreads();
+    const float fstar = key2f(P.acc[ao.seq].res_key);
+    const int p = p0 + tid;
+    // a_p: prefix of the undeleted chain; lane p keeps the value before position p
+    float v = add_run_d0(d0, 0, p0, 0.0f);
+    float mine = v;
+    const int pend = min(p0 + 256, L2 - 1);  // p <= L2 - 2
+    for (int j = p0; j < pend; ++j) {
+      mine = (j == p) ? v : mine;
+      v += d0[j];
+    }
+    // skewed chain: step t handles position p + 1 + t
+    const float2 *dp = d12 + p + 1;
+    const int nsteps = L2 - 1 - p0;
+    float c = -INFINITY;
+    v = mine;
+    int t = 0;
+    for (; t + 4 <= nsteps; t += 4) {
+      const float2 x0 = dp[t], x1 = dp[t + 1], x2 = dp[t + 2], x3 = dp[t + 3];
+      c = fmaxf(v, c + x0.y); v = v + x0.x;
+      c = fmaxf(v, c + x1.y); v = v + x1.x;
+      c = fmaxf(v, c + x2.y); v = v + x2.x;
+      c = fmaxf(v, c + x3.y); v = v + x3.x;
+    }
+    for (; t < nsteps; ++t) {
+      const float2 x = dp[t];
+      c = fmaxf(v, c + x.y);
+      v = v + x.x;
+    }
+    int cand = (p <= L2 - 2 && c == fstar) ? p : INT_MAX;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cand = min(cand, __shfl_xor(cand, m));
+    if ((tid & 63) == 0 && cand != INT_MAX) atomicMin(&P.acc[ao.seq].res_p, cand);
+  }
+}
+
+// pass 4: with p* fixed, lane q evaluates score(s,p*,q) exactly as the reference adds
+// it: the one-deletion chain value before position q, then d2[j] for j > q (skewed in
+// time like pass 3).  The smallest q, then the smallest offset, wins.
+__global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
+  __shared__ int skip_flag[1];
+  float *T = (float *)smem;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kDevTable; i += 256) T[i] = P.table_t[i];
+  const unsigned nact = *P.nactive;
+  const long long nitems = (long long)nact * P.pchunks;
+  for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+    ActiveOffset ao;
+    ao.seq = uni(P.active[item / P.pchunks].seq);
+    ao.s = uni(P.active[item / P.pchunks].s);
+    const int qc = (int)(item % P.pchunks);
+    const SeqDesc d = load_desc(P.desc + ao.seq);
+    const int L2 = d.len2;
+    const int pstar = uni(P.acc[ao.seq].res_p);
+    const int q0 = qc * 256;
+    if (pstar == INT_MAX || q0 > L2 - 1 || q0 + 255 <= pstar) continue;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long known = P.acc[ao.seq].res_loc;
+      skip_flag[0] = known != ~0ull && (int)(known >> 32) < q0;  // a smaller q is already known
+    }
+    __syncthreads();
+    if (uni(skip_flag[0])) continue;  // one decision for the whole block
+    float *d0 = T + kDevTable;
+    float2 *d12 = (float2 *)(d0 + tie_d0_len(L2));
+    fill_diagonals(d0, d12, T, P, d, ao.s);
+    __syncthreads();
+    const float fstar = key2f(P.acc[ao.seq].res_key);
+    const int q = q0 + tid;
+    float v = add_run_d0(d0, 0, pstar, 0.0f);  // a_{p*}
+    int j = pstar + 1;
+    for (; j < q0; ++j) v += d12[j].x;         // positions every lane of the block consumes
+    float mine = v;
+    const int qend = min(q0 + 256, L2);
+    for (; j < qend; ++j) {
+      mine = (j == q) ? v : mine;               // value handed over when q is deleted
+      v += d12[j].x;
+    }
+    const float2 *dp = d12 + q + 1;
+    const int nsteps = L2 - 1 - q0;
+    float c = mine;
+    int t = 0;
+    for (; t + 4 <= nsteps; t += 4) {
+      const float y0 = dp[t].y, y1 = dp[t + 1].y, y2 = dp[t + 2].y, y3 = dp[t + 3].y;
+      c += y0;
+      c += y1;
+      c += y2;
+      c += y3;
+    }
+    for (; t < nsteps; ++t) c += dp[t].y;
+    unsigned long long cand = ~0ull;
+    if (q > pstar && q <= L2 - 1 && c == fstar) cand = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)ao.s;
+    cand = wave_min_u64(cand);
+    if ((tid & 63) == 0 && cand != ~0ull) atomicMin(&P.acc[ao.seq].res_loc, cand);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// result records: decode the accumulators and count residue classes of the winners
+// ---------------------------------------------------------------------------------
+__device__ void count_classes(const FinalParams &P, const SeqDesc &d, int s, int p, int q, int *lds_counts,
+                              int32_t *out) {
+  const int tid = threadIdx.x;
+  if (tid < 4) lds_counts[tid] = 0;
+  __syncthreads();
+  int local[4] = {0, 0, 0, 0};
+  const int m = d.len2 - 2;
+  for (int i = tid; i < m; i += blockDim.x) {
+    const int j = i < p ? i : (i < q - 1 ? i + 1 : i + 2);
+    const int a = P.seq1[(int64_t)s + i], b = P.seq2_pool[d.off2 + j];
+    const int cls = P.class_t[b * kRowStride + a];
+    local[0] += cls == 0;
+    local[1] += cls == 1;
+    local[2] += cls == 2;
+    local[3] += cls == 3;
+  }
+  for (int k = 0; k < 4; ++k)
+    if (local[k]) atomicAdd(&lds_counts[k], local[k]);
+  __syncthreads();
+  if (tid < 4) out[tid] = lds_counts[tid];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
+  __shared__ int lds_counts[4];
+  const int i = blockIdx.x;
+  const SeqDesc d = P.desc[i];
+  const SeqAcc a = P.acc[i];
+  psa_result *r = P.out + i;
+  const int tid = threadIdx.x;
+  const bool res_ok = uni((P.stages & PSA_STAGE_RESOLVE) && a.res_loc != ~0ull && a.res_p != INT_MAX);
+  const bool enum_ok = uni((P.stages & PSA_STAGE_ENUMERATE) && d.frac_bits >= 0 && a.enum_loc != ~0ull);
+  if (res_ok) {
+    const int p = a.res_p, q = (int)(a.res_loc >> 32), s = (int)(uint32_t)a.res_loc;
+    count_classes(P, d, s, p, q, lds_counts, r->counts);
+    if (tid == 0) {
+      r->n = p + 1;
+      r->k = q + 1;
+      r->offset = s;
+      const float sc = key2f(a.res_key);
+      r->score = sc;
+      r->score_bits = __float_as_uint(sc);
+      const long long L = d.len2, n = p + 1;
+      r->mutant_num = (int32_t)((n - 1) * L - n * (n - 1) / 2 + (q - p) - 1);
+    }
+  } else if (tid == 0) {
+    r->n = r->k = r->offset = r->mutant_num = 0;
+    r->score = 0.0f;
+    r->score_bits = 0u;
+    r->counts[0] = r->counts[1] = r->counts[2] = r->counts[3] = 0;
+  }
+  if (enum_ok) {
+    const int p = (int)(0xffffffffu - (uint32_t)a.enum_key);
+    const int q = (int)(a.enum_loc >> 32), s = (int)(uint32_t)a.enum_loc;
+    count_classes(P, d, s, p, q, lds_counts, r->enum_counts);
+    if (tid == 0) {
+      r->enum_n = p + 1;
+      r->enum_k = q + 1;
+      r->enum_offset = s;
+      r->enum_score = (int)((uint32_t)(a.enum_key >> 32) ^ 0x80000000u);
+    }
+  } else if (tid == 0) {
+    r->enum_n = r->enum_k = r->enum_offset = r->enum_score = 0;
+    r->enum_counts[0] = r->enum_counts[1] = r->enum_counts[2] = r->enum_counts[3] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------
+// With PSA_DEBUG_SYNC set in the environment every launch is followed by a device
+// synchronisation and a line on stderr naming the kernel that just finished.
+hipError_t debug_sync(const char *what) {
+  static const bool on = getenv("PSA_DEBUG_SYNC") != nullptr;
+  if (!on) return hipSuccess;
+  hipError_t e = hipDeviceSynchronize();
+  fprintf(stderr, "[psa] %s: %s\n", what, hipGetErrorString(e));
+  fflush(stderr);
+  return e;
+}
+
+hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hipStream_t st) {
+  int m = n > ncounters ? n : ncounters;
+  hipLaunchKernelGGL(psa_init_acc, dim3((m + 255) / 256), dim3(256), 0, st, acc, n, counters, ncounters);
+  return hipGetLastError();
+}
+
+static size_t fwd_lds(int max_len2) {
+  return (size_t)kDevTable * 4 + 4 * (size_t)fwd_bwords(max_len2) + 4 * (size_t)fwd_window(max_len2) + 64;
+}
+static size_t tie_lds(int max_len2) {
+  return (size_t)kDevTable * 4 + 4 * (size_t)tie_d0_len(max_len2) + 8 * (size_t)tie_d12_len(max_len2);
+}
+
+hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st) {
+  static size_t attr_bytes = 0;
+  hipError_t e;
+  const size_t tb = tie_lds(max_len2);
+  if (tb > attr_bytes) {
+    e = hipFuncSetAttribute((const void *)psa_first_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)psa_first_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)psa_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)fwd_lds(PSA_MAX_SEQ2));
+    if (e != hipSuccess) return e;
+    attr_bytes = tb;
+  }
+  hipLaunchKernelGGL(psa_fwd, dim3(nfwd_blocks), dim3(256), fwd_lds(max_len2), st, P);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = debug_sync("psa_fwd")) != hipSuccess) return e;
+  hipLaunchKernelGGL(psa_collect, dim3(nfwd_blocks), dim3(256), 0, st, P);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = debug_sync("psa_collect")) != hipSuccess) return e;
+  hipLaunchKernelGGL(psa_first_p, dim3(tie_grid), dim3(256), tb, st, P);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = debug_sync("psa_first_p")) != hipSuccess) return e;
+  hipLaunchKernelGGL(psa_first_q, dim3(tie_grid), dim3(256), tb, st, P);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return debug_sync("psa_first_q");
+}
+
+hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st) {
+  hipLaunchKernelGGL(psa_finalize, dim3(n), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
+
+}  // namespace psa
