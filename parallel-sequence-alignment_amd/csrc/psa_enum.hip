@@ -92,11 +92,12 @@ __device__ __forceinline__ void enum_full(const int *gL, int qa, int qb, const i
 #pragma unroll 2
   for (int u = 0; u < n; ++u) {
     const int4 nxt = g4[u + 1];  // one group ahead; the last read lands in the slack after g
+    // two passes over the registers, so that consecutive max3 instructions never
+    // update the same accumulator (a dependent pair would stall the issue)
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-      acc[r] = max3i(acc[r], f[r] + cur.x, f[r] + cur.y);
-      acc[r] = max3i(acc[r], f[r] + cur.z, f[r] + cur.w);
-    }
+    for (int r = 0; r < K; ++r) acc[r] = max3i(acc[r], f[r] + cur.x, f[r] + cur.y);
+#pragma unroll
+    for (int r = 0; r < K; ++r) acc[r] = max3i(acc[r], f[r] + cur.z, f[r] + cur.w);
     cur = nxt;
   }
 }
@@ -173,8 +174,12 @@ __device__ __forceinline__ void enum_chunk_setup(unsigned char *smem, const Enum
   scan_diagonal<NT, R>(smem, bro, ch.s0 - 1, win0);
 }
 
+// waves per SIMD the register budget is sized for: 8 (at most 64 VGPRs) except for the
+// largest variant, whose 32 running maxima and f values per lane need 128
+constexpr int enum_waves_per_simd(int nt, int r) { return nt * r > 4096 ? 4 : 8; }
+
 template <int NT, int R>
-__global__ __launch_bounds__(NT) void psa_enum_main(EnumParams P) {
+__global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_main(EnumParams P) {
   using L = EnumLds<NT, R>;
   constexpr int NW = NT / 64;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(NT) void psa_enum_main(EnumParams P) {
 // smallest q and then the smallest offset with f_s[p*] + g_s[q] == G.  Only chunks
 // whose own (maximum, p) equals the Seq2's can contain such a candidate.
 template <int NT, int R>
-__global__ __launch_bounds__(NT) void psa_enum_locate(EnumParams P) {
+__global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locate(EnumParams P) {
   using L = EnumLds<NT, R>;
   constexpr int NW = NT / 64;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -331,7 +336,7 @@ int enum_class_of(int len2) {
 }
 
 int enum_class_positions(int c) {
-  static const int np[kEnumClasses] = {256 * 1, 256 * 2, 256 * 4, 256 * 8, 256 * 16, 512 * 16};
+  static const int np[kEnumClasses] = {256 * 1, 256 * 2, 512 * 2, 512 * 4, 1024 * 4, 1024 * 8};
   return np[c];
 }
 
@@ -339,24 +344,24 @@ int enum_class_lds_bytes(int c) {
   switch (c) {
     case 0: return EnumLds<256, 1>::total;
     case 1: return EnumLds<256, 2>::total;
-    case 2: return EnumLds<256, 4>::total;
-    case 3: return EnumLds<256, 8>::total;
-    case 4: return EnumLds<256, 16>::total;
-    default: return EnumLds<512, 16>::total;
+    case 2: return EnumLds<512, 2>::total;
+    case 3: return EnumLds<512, 4>::total;
+    case 4: return EnumLds<1024, 4>::total;
+    default: return EnumLds<1024, 8>::total;
   }
 }
 
-int enum_class_threads(int c) { return c == 5 ? 512 : 256; }
+int enum_class_threads(int c) { return c < 2 ? 256 : (c < 4 ? 512 : 1024); }
 
 hipError_t launch_enum(int cls, const EnumParams &P, int grid_main, int grid_locate, hipStream_t st,
                        hipEvent_t ev_begin, hipEvent_t ev_end) {
   switch (cls) {
     case 0: return launch_enum_t<256, 1>(P, grid_main, grid_locate, st, ev_begin, ev_end);
     case 1: return launch_enum_t<256, 2>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 2: return launch_enum_t<256, 4>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 3: return launch_enum_t<256, 8>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 4: return launch_enum_t<256, 16>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 5: return launch_enum_t<512, 16>(P, grid_main, grid_locate, st, ev_begin, ev_end);
+    case 2: return launch_enum_t<512, 2>(P, grid_main, grid_locate, st, ev_begin, ev_end);
+    case 3: return launch_enum_t<512, 4>(P, grid_main, grid_locate, st, ev_begin, ev_end);
+    case 4: return launch_enum_t<1024, 4>(P, grid_main, grid_locate, st, ev_begin, ev_end);
+    case 5: return launch_enum_t<1024, 8>(P, grid_main, grid_locate, st, ev_begin, ev_end);
     default: return hipErrorInvalidValue;
   }
 }
