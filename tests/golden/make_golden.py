@@ -11,7 +11,8 @@ bits of the score -- for
 The output, golden.json, holds inputs and expected outputs only.
 
 usage: python tests/golden/make_golden.py [--full]
-  --full also runs the reference on its large input.txt (about 15 minutes).
+  --full also runs the reference on its large input.txt (about 15 minutes); without it the
+  case is taken from ref_input_reference_stdout.txt, the saved stdout of such a run.
 """
 import json
 import os
@@ -36,6 +37,19 @@ SAMPLES = [
     (os.path.join(REF_P, "input1.txt"), "ref_p_input1.txt"),
     (os.path.join(REF_S, "input.txt"), "ref_input.txt"),
 ]
+
+
+def parse_stdout(text):
+    """result lines of the compiled reference (see oracle/ref_hook.h) -> expected records"""
+    res, last = [], None
+    for line in text.splitlines():
+        if line.startswith("MS("):
+            last = line
+        elif line.startswith("PSA_REF_BITS"):
+            kv = dict(x.split("=") for x in line.split()[1:])
+            res.append({"n": int(kv["n"]), "k": int(kv["k"]), "offset": int(kv["offset"]),
+                        "bits": int(kv["bits"], 16), "text": last})
+    return res
 
 
 def parse_input(path):
@@ -104,10 +118,16 @@ def main():
     for src, name in SAMPLES:
         dst = os.path.join(HERE, "inputs", name)
         shutil.copyfile(src, dst)
-        if name == "ref_input.txt" and not full:
-            continue
         weights, seq1, seq2s = parse_input(dst)
-        res = oracle_py.run_reference(dst)
+        if name == "ref_input.txt" and not full:
+            res = parse_stdout(open(os.path.join(HERE, "ref_input_reference_stdout.txt")).read())
+        else:
+            res = oracle_py.run_reference(dst)
+            if name == "ref_input.txt":
+                env = dict(os.environ, PSA_REF_INPUT=dst)
+                import subprocess
+                open(os.path.join(HERE, "ref_input_reference_stdout.txt"), "w").write(
+                    subprocess.run([oracle_py.REF_BIN], env=env, cwd="/tmp", capture_output=True, text=True).stdout)
         assert len(res) == len(seq2s)
         cases.append({"name": name, "source": "reference sample input", "weights": weights, "seq1": seq1,
                       "seq2": seq2s, "expected": res})
@@ -122,11 +142,6 @@ def main():
                       "weights": w.split(), "seq1": seq1, "seq2": seq2s, "expected": res})
     shutil.rmtree(tmp)
     out = os.path.join(HERE, "golden.json")
-    if not full and os.path.exists(out):
-        # keep a previously recorded full-size case
-        old = json.load(open(out))
-        keep = [c for c in old["cases"] if c["name"] == "ref_input.txt"]
-        cases = keep + cases
     json.dump({"generator": "tests/golden/make_golden.py", "cases": cases}, open(out, "w"), indent=0)
     print("wrote", out, len(cases), "files,", sum(len(c["seq2"]) for c in cases), "Seq2 cases")
 

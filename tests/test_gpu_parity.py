@@ -198,6 +198,61 @@ def test_dropin_shim(psa, oracle, golden, capfd):
                                                                                    e["offset"])
 
 
+def _expected_lines(psa, case):
+    out = []
+    for seq2, e in zip(case["seq2"], case["expected"]):
+        score = np.array([e["bits"]], dtype=np.uint32).view(np.float32)[0]
+        mnum = psa.mutant_number(e["n"], e["k"], len(seq2)) - 1
+        out.append("mutant num: %d, MS(%d,%d), score: %1.2f, offset: %d\n" % (mnum, e["n"], e["k"], score, e["offset"]))
+    return out
+
+
+def test_host_program_files(psa, golden, tmp_path):
+    """input.txt -> output.txt through the C++ driver (psa_host) and the Python one."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "parallel-sequence-alignment_amd", "psa_host")
+    assert os.path.exists(exe), "psa_host not built"
+    from psa_amd import host
+    for name in ("ref_s_input3.txt", "ref_p_input1.txt", "ref_input.txt"):
+        case = [c for c in golden if c["name"] == name][0]
+        inp = os.path.join(root, "tests", "golden", "inputs", name)
+        out = tmp_path / ("out_" + name)
+        r = subprocess.run([exe, inp, str(out), "1"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        want = _expected_lines(psa, case)
+        assert open(out).read().splitlines(keepends=True) == want
+        assert all(line in r.stdout for line in want)
+        out2 = tmp_path / ("pyout_" + name)
+        assert host.run(inp, str(out2), echo=False) == want
+        assert open(out2).read().splitlines(keepends=True) == want
+
+
+def test_config3_shape_small(psa, ctx, oracle):
+    """Batch of Seq2 of mixed lengths (every kernel variant in one launch set) against Seq1 = 10000."""
+    rng = np.random.default_rng(33)
+    lens = [int(x) for x in rng.integers(500, 2001, size=24)] + [40, 300, 2048, 2100]
+    seq1, seq2s = synth_problem(34, 10000, lens)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+
+
+def test_long_seq2(psa, ctx, oracle):
+    """Seq2 of 4095/4096/8000/8191 characters: the two largest kernel variants."""
+    seq1, seq2s = synth_problem(77, 9000, [4095, 4096, 8000, 8191])
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+    res = ctx.score_batch(["A" * 8192])
+    assert res[0].status == 3
+
+
 def test_authors_recorded_output(psa):
     """P/output.txt:1-4 -- what the CUDA program wrote for P/input.txt."""
     import os
