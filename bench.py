@@ -111,6 +111,20 @@ def cpu_baseline(seq1, seq2, budget_s=12.0):
                       % (S, n1, t1, nm, cores, tm, L2, L1)}
 
 
+def measured_traffic(cfg):
+    """HBM bytes per launch of the enumeration kernel as the TCC counters saw them in the committed
+    rocprofv3 run of this workload (profiles/r01_c2_pmc.json); None for workloads not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
+    if cfg != "c2" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        kernels = json.load(f)["kernels"]
+    for name, c in kernels.items():
+        if "psa_enum_main" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,11 +223,12 @@ def main():
             out["roofline"] = {
                 "bound": "valu-int32", "kernel": "psa_enum_main",
                 "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
-                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": None,
+                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config),
+                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run)",
                 "kernel_ms": kern_s * 1e3,
                 "note": "2 int32 lane-ops (add + max) per candidate x candidates per launch / HIP-event time of "
-                        "the enumeration kernel on its own stream; HBM traffic is a few KB per launch "
-                        "(Seq1 + Seq2 bytes), so neither HBM nor MFMA bounds this kernel",
+                        "the enumeration kernel on its own stream; the kernel reads Seq1 + Seq2 (a few KB) and "
+                        "writes one 8-byte key per chunk, so neither HBM nor MFMA bounds it",
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(seq1, seq2s[0])
