@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--nseq2", type=int, default=256, help="Seq2 per GPU for --config c3")
     ap.add_argument("--stages", default="both", choices=["both", "enumerate", "resolve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -144,12 +147,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:  # gloo: rehearsal of the N > 1 logic where the ranks cannot each have a GPU of their own
+            dist.init_process_group(args.backend)
+    cdev = "cuda" if args.backend == "nccl" else "cpu"  # where the few collective payloads live
 
     import psa_amd
     name, seq1, seq2s, rng = make_workload(args.config, rank, world, args.nseq2)
@@ -185,7 +194,7 @@ def main():
         raise SystemExit("workload has invalid Seq2: %r" % bad)
     cand_rank = sum(r.candidates for r in res)
     if dist is not None:
-        t = torch.tensor([elapsed, float(cand_rank), enum_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(cand_rank), enum_ms], dtype=torch.float64, device=cdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -193,7 +202,7 @@ def main():
         elapsed, cand_total = float(tmax[0]), float(tsum[1])
         if args.config == "c4":  # one long pair: the job's answer is the max-loc combine of the shards
             rec = np.frombuffer(bytes(res[0]), dtype=np.uint8).copy()
-            mine = torch.from_numpy(rec).cuda()
+            mine = torch.from_numpy(rec).to(cdev)
             allrec = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(allrec, mine)
             parts = [psa_amd.Result.from_buffer_copy(bytes(x.cpu().numpy())) for x in allrec]

@@ -253,6 +253,45 @@ def test_long_seq2(psa, ctx, oracle):
     assert res[0].status == 3
 
 
+def test_config4_full_size(psa, ctx, oracle):
+    """Seq1 = 200000, Seq2 = 8000 (6.1e12 candidates): whole range against the O(L1*L2) oracle, and
+    two offset shards combining to the same record."""
+    seq1, seq2s = synth_problem(4, 200000, [8000])
+    seq2 = seq2s[0]
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    whole = ctx.score_batch([seq2])[0]
+    check_against_oracle(oracle, seq1, [seq2], table, [whole])
+    S = len(seq1) - len(seq2) + 3
+    parts = [ctx.score_range(seq2, 0, S // 2, psa.STAGE_RESOLVE), ctx.score_range(seq2, S // 2, S, psa.STAGE_RESOLVE)]
+    assert psa.combine_results(parts).key() == whole.key()
+
+
+def test_config3_batch_properties(psa, ctx, oracle):
+    """A batch of 384 Seq2 of 500..2000 characters against Seq1 = 10000: results do not depend on
+    the order or the company a Seq2 is scored in, and a sample equals the oracle."""
+    rng = np.random.default_rng(303)
+    lens = [int(x) for x in rng.integers(500, 2001, size=384)]
+    seq1, seq2s = synth_problem(304, 10000, lens)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    res = ctx.score_batch(seq2s)
+    perm = rng.permutation(len(seq2s))
+    res_p = ctx.score_batch([seq2s[i] for i in perm])
+    for j, i in enumerate(perm):
+        assert res_p[j].key() == res[i].key() and res_p[j].enum_key() == res[i].enum_key()
+        assert tuple(res_p[j].counts) == tuple(res[i].counts)
+    sample = [int(i) for i in rng.choice(len(seq2s), size=10, replace=False)]
+    check_against_oracle(oracle, seq1, [seq2s[i] for i in sample], table, [res[i] for i in sample])
+    alone = ctx.score_batch([seq2s[sample[0]]])[0]
+    assert alone.key() == res[sample[0]].key() and alone.enum_key() == res[sample[0]].enum_key()
+    assert sum(r.candidates for r in res) == sum((10000 - L + 3) * (L * (L - 1) // 2) for L in lens)
+
+
 def test_authors_recorded_output(psa):
     """P/output.txt:1-4 -- what the CUDA program wrote for P/input.txt."""
     import os
