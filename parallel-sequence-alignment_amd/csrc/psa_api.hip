@@ -24,8 +24,9 @@ thread_local std::string g_err;
     }                                                                                      \
   } while (0)
 
-constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kResolveHeadroom = 40 * 1024;
+constexpr size_t kSlabUnit = 256;                 // bytes: one run of 64 int32
+constexpr size_t kSlabMinUnits = (5u << 20) / 256;  // the largest chunk (64 offsets x (2 x 128 + 1) runs) fits
+constexpr size_t kSlabDefaultMiB = 2048;
 
 template <class T>
 int upload(T **dptr, const std::vector<T> &h) {
@@ -41,7 +42,13 @@ int upload(T **dptr, const std::vector<T> &h) {
 struct psa_ctx {
   int device = 0;
   int num_cus = 256;
-  hipStream_t st_enum = nullptr, st_res = nullptr;
+  hipStream_t st_enum = nullptr, st_res = nullptr, st_pre = nullptr;
+  // f/g rows of the enumeration stage: the pre-pass fills one slab while the candidate
+  // loop reads the other.  Grown on demand, shared by the batches of the context.
+  int *d_slab[2] = {nullptr, nullptr};
+  size_t slab_units = 0;  // capacity of each slab in runs of 64 int32
+  int slab_count = 0;
+  hipEvent_t ev_prep[2] = {nullptr, nullptr};
   unsigned char *d_seq1 = nullptr;
   int64_t len1 = 0;
   float table[PSA_TABLE_SIZE];
@@ -61,11 +68,20 @@ struct psa_batch {
   unsigned char *d_pool = nullptr;
   psa::SeqDesc *d_desc = nullptr;
   psa::SeqAcc *d_acc = nullptr;
-  unsigned *d_counters = nullptr;  // kEnumClasses work counters + the active-offset count
-  psa::Chunk *d_chunks[psa::kEnumClasses] = {};
-  unsigned long long *d_chunk_best[psa::kEnumClasses] = {};
-  int nchunks[psa::kEnumClasses] = {};
-  int grid[psa::kEnumClasses] = {};
+  unsigned *d_counters = nullptr;  // [0] = the active-offset count
+  // enumeration stage: chunks sorted by falling Seq2 length; a slab pass covers chunks
+  // [c0, c1), whose rows fit one slab
+  struct SlabPass {
+    int c0 = 0, c1 = 0;
+    int cls_c0[psa::kEnumClasses + 1] = {};  // chunks of kernel class k: [cls_c0[k + 1], cls_c0[k]) (classes fall)
+    psa::WaveParams wave{};
+    hipEvent_t ev_b = nullptr, ev_e = nullptr;
+  };
+  std::vector<SlabPass> passes;
+  psa::Chunk *d_chunks = nullptr;
+  unsigned long long *d_chunk_best = nullptr;
+  int nchunks = 0;
+  int cls_c0[psa::kEnumClasses + 1] = {};  // the same over the whole chunk list
   psa::FwdBlock *d_fwd = nullptr;
   int nfwd = 0;
   float *d_fs = nullptr;
@@ -73,11 +89,9 @@ struct psa_batch {
   psa_result *d_out = nullptr;
   psa_result *h_out = nullptr;  // pinned
   hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_init = nullptr, ev_res = nullptr;
-  hipEvent_t ev_b[psa::kEnumClasses] = {}, ev_e[psa::kEnumClasses] = {};
   uint32_t last_stages = 0xffffffffu;  // stages of the previous run
   hipGraphExec_t graph_exec = nullptr;  // replayable capture of one run
   uint32_t graph_stages = 0;
-  bool graph_timed[psa::kEnumClasses] = {};
   bool graph_failed = false;
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
@@ -115,6 +129,8 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   PSA_HIP(hipStreamCreateWithPriority(&c->st_enum, hipStreamNonBlocking, prio_low));
   PSA_HIP(hipStreamCreateWithPriority(&c->st_res, hipStreamNonBlocking, prio_high));
+  PSA_HIP(hipStreamCreateWithPriority(&c->st_pre, hipStreamNonBlocking, prio_high));
+  for (hipEvent_t &e : c->ev_prep) PSA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
   std::vector<unsigned char> cls(psa::kDevTable, 3);
@@ -133,6 +149,11 @@ void psa_shutdown(psa_ctx *c) {
   if (c->d_class_t) (void)hipFree(c->d_class_t);
   if (c->st_enum) (void)hipStreamDestroy(c->st_enum);
   if (c->st_res) (void)hipStreamDestroy(c->st_res);
+  if (c->st_pre) (void)hipStreamDestroy(c->st_pre);
+  for (int *p : c->d_slab)
+    if (p) (void)hipFree(p);
+  for (hipEvent_t e : c->ev_prep)
+    if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -185,11 +206,11 @@ void psa_batch_destroy(psa_batch *b) {
   if (b->d_desc) (void)hipFree(b->d_desc);
   if (b->d_acc) (void)hipFree(b->d_acc);
   if (b->d_counters) (void)hipFree(b->d_counters);
-  for (int c = 0; c < psa::kEnumClasses; ++c) {
-    if (b->d_chunks[c]) (void)hipFree(b->d_chunks[c]);
-    if (b->d_chunk_best[c]) (void)hipFree(b->d_chunk_best[c]);
-    if (b->ev_b[c]) (void)hipEventDestroy(b->ev_b[c]);
-    if (b->ev_e[c]) (void)hipEventDestroy(b->ev_e[c]);
+  if (b->d_chunks) (void)hipFree(b->d_chunks);
+  if (b->d_chunk_best) (void)hipFree(b->d_chunk_best);
+  for (psa_batch::SlabPass &sp : b->passes) {
+    if (sp.ev_b) (void)hipEventDestroy(sp.ev_b);
+    if (sp.ev_e) (void)hipEventDestroy(sp.ev_e);
   }
   if (b->d_fwd) (void)hipFree(b->d_fwd);
   if (b->d_fs) (void)hipFree(b->d_fs);
@@ -216,9 +237,8 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   b->desc.resize((size_t)n);
   b->tmpl.assign((size_t)n, psa_result{});
   std::vector<unsigned char> pool;
-  std::vector<psa::Chunk> chunks[psa::kEnumClasses];
+  std::vector<psa::Chunk> chunks;
   std::vector<psa::FwdBlock> fwd;
-  int64_t class_offsets[psa::kEnumClasses] = {};
   int64_t fs_total = 0;
 
   for (int i = 0; i < n; ++i) {
@@ -275,39 +295,100 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     r.status = PSA_OK;
     b->max_len2 = std::max<int>(b->max_len2, (int)L2);
     b->nvalid++;
-    if (d.frac_bits >= 0) class_offsets[psa::enum_class_of((int)L2)] += se - sb;
     for (int64_t s0 = sb; s0 < se; s0 += 256) fwd.push_back(psa::FwdBlock{i, (int32_t)s0});
   }
   b->total_offsets = fs_total;
 
-  // enumeration chunks: a few offsets each, longest Seq2 first so that the work
-  // counter hands out the expensive chunks early
+  // Enumeration chunks, longest Seq2 first.  A wave of psa_enum_wave scores enum_ns
+  // offsets x 256 positions p; a chunk (the pre-pass unit) is 2^sub_log2 such sub-runs.
   std::vector<int> order;
   for (int i = 0; i < n; ++i)
     if (b->tmpl[(size_t)i].status == PSA_OK && b->desc[(size_t)i].frac_bits >= 0) order.push_back(i);
   std::stable_sort(order.begin(), order.end(),
                    [&](int x, int y) { return b->desc[(size_t)x].len2 > b->desc[(size_t)y].len2; });
-  int resident[psa::kEnumClasses];
-  for (int k = 0; k < psa::kEnumClasses; ++k) {
-    // leave kResolveHeadroom bytes of LDS per CU free so that blocks of the resolve
-    // kernels can be placed while the persistent enumeration blocks are resident
-    // (only where at least three enumeration blocks per CU remain)
-    const size_t lds = (size_t)psa::enum_class_lds_bytes(k);
-    const size_t with_room = (kLdsPerCu - kResolveHeadroom) / lds;
-    int per_cu = (int)std::min<size_t>(with_room >= 3 ? with_room : kLdsPerCu / lds,
-                                       (size_t)(2048 / psa::enum_class_threads(k)));
-    per_cu = std::max(1, std::min(per_cu, 8));
-    if (const char *e = std::getenv("PSA_ENUM_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));  // tuning aid
-    resident[k] = per_cu * c->num_cus;
-  }
+  constexpr int RW = psa::kEnumWaveRuns;
+  auto runs_of = [](int len2) { return (len2 + 63) / 64; };
+  auto levels_of = [&](int len2) { return (runs_of(len2) + RW - 1) / RW; };
+  int64_t row_units = 0;
   for (int i : order) {
     const psa::SeqDesc &d = b->desc[(size_t)i];
-    const int k = psa::enum_class_of(d.len2);
-    int64_t ns = class_offsets[k] / ((int64_t)resident[k] * 8);
+    row_units += (int64_t)(d.s_end - d.s_begin) * levels_of(d.len2);
+  }
+  // enough units to keep every wave slot busy many times over, each unit long enough
+  // (about 30 us: 72000 cycles at ~333 cycles per 64 x 64 candidates) to hide its start-up
+  const int64_t ns_cap = std::max<int64_t>(1, row_units / (16 * (int64_t)c->num_cus * 32));
+  int min_ns = psa::kEnumMaxNs;
+  for (int i : order) {
+    psa::SeqDesc &d = b->desc[(size_t)i];
+    const int64_t unit_cycles = (int64_t)std::max(1, runs_of(d.len2) - RW) * RW * 333;
+    int64_t ns = std::min<int64_t>(std::max<int64_t>(1, (72000 + unit_cycles / 2) / unit_cycles), ns_cap);
     if (const char *e = std::getenv("PSA_ENUM_NS")) ns = std::atoi(e);  // tuning aid
-    ns = std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
-    for (int64_t s0 = d.s_begin; s0 < d.s_end; s0 += ns)
-      chunks[k].push_back(psa::Chunk{i, (int32_t)s0, (int32_t)std::min<int64_t>(ns, d.s_end - s0), 0});
+    d.enum_ns = (int32_t)std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
+    min_ns = std::min(min_ns, d.enum_ns);
+  }
+  int sub_log2 = min_ns >= 8 ? 0 : (min_ns >= 4 ? 1 : (min_ns >= 2 ? 2 : 3));
+  if (const char *e = std::getenv("PSA_ENUM_SUB_LOG2")) sub_log2 = std::max(0, std::min(3, std::atoi(e)));  // tuning aid
+  size_t total_units = 0;
+  for (int i : order) {
+    const psa::SeqDesc &d = b->desc[(size_t)i];
+    const int64_t per = std::min<int64_t>((int64_t)d.enum_ns << sub_log2, psa::kEnumMaxNs);
+    for (int64_t s0 = d.s_begin; s0 < d.s_end; s0 += per) {
+      const int64_t cnt = std::min<int64_t>(per, d.s_end - s0);
+      chunks.push_back(psa::Chunk{i, (int32_t)s0, (int32_t)cnt, 0u});
+      total_units += (size_t)cnt * (2 * (size_t)runs_of(d.len2) + 1);
+    }
+  }
+  // slab passes: consecutive chunks whose rows fit one slab
+  size_t cap_units = kSlabDefaultMiB * ((1u << 20) / kSlabUnit);
+  if (const char *e = std::getenv("PSA_SLAB_MB")) cap_units = (size_t)std::max(1, std::atoi(e)) * ((1u << 20) / kSlabUnit);
+  cap_units = std::max(kSlabMinUnits, std::min(cap_units, total_units));
+  {
+    size_t used = 0;
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      psa::Chunk &ch = chunks[ci];
+      const size_t need = (size_t)ch.ns * (2 * (size_t)runs_of(b->desc[(size_t)ch.seq].len2) + 1);
+      if (b->passes.empty() || used + need > cap_units) {
+        if (!b->passes.empty()) b->passes.back().c1 = (int)ci;
+        b->passes.emplace_back();
+        b->passes.back().c0 = (int)ci;
+        used = 0;
+      }
+      ch.fg_row = (uint32_t)used;
+      used += need;
+    }
+    if (!b->passes.empty()) b->passes.back().c1 = (int)chunks.size();
+  }
+  auto class_bounds = [&](int c0, int c1, int *out) {
+    // chunks [c0, c1) are sorted by falling length, so kernel classes fall too:
+    // class k owns [out[k + 1], out[k])
+    int pos = c0;
+    out[psa::kEnumClasses] = c0;
+    for (int k = psa::kEnumClasses - 1; k >= 0; --k) {
+      while (pos < c1 && psa::enum_class_of(b->desc[(size_t)chunks[(size_t)pos].seq].len2) == k) ++pos;
+      out[k] = pos;
+    }
+  };
+  class_bounds(0, (int)chunks.size(), b->cls_c0);
+  for (psa_batch::SlabPass &sp : b->passes) {
+    class_bounds(sp.c0, sp.c1, sp.cls_c0);
+    psa::WaveParams &W = sp.wave;
+    W.sub_log2 = sub_log2;
+    int64_t base = 0;
+    int prefix = sp.c1 - sp.c0;  // chunks that have level w: a prefix of the pass, shrinking as w grows
+    for (int w = 0; w <= psa::kEnumMaxLevels; ++w) W.level_base[w] = INT32_MAX;
+    W.level_base[0] = 0;
+    for (int w = 0; w < psa::kEnumMaxLevels; ++w) {
+      while (prefix > 0 && levels_of(b->desc[(size_t)chunks[(size_t)(sp.c0 + prefix - 1)].seq].len2) <= w) --prefix;
+      if (prefix == 0) break;
+      W.level_base[w] = (int)std::min<int64_t>(base, INT32_MAX);
+      base += (int64_t)prefix << sub_log2;
+    }
+    if (base > INT32_MAX) {
+      g_err = "too many enumeration units in one slab pass";
+      psa_batch_destroy(b);
+      return PSA_ERR_ARG;
+    }
+    W.nunits = (int)base;
   }
 
   int st = PSA_OK;
@@ -319,15 +400,38 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   if ((st = upload(&b->d_desc, b->desc)) != PSA_OK) return fail(st);
   if ((st = upload(&b->d_fwd, fwd)) != PSA_OK) return fail(st);
   b->nfwd = (int)fwd.size();
-  for (int k = 0; k < psa::kEnumClasses; ++k) {
-    if ((st = upload(&b->d_chunks[k], chunks[k])) != PSA_OK) return fail(st);
-    if (!chunks[k].empty() &&
-        hipMalloc((void **)&b->d_chunk_best[k], chunks[k].size() * sizeof(unsigned long long)) != hipSuccess) {
+  if ((st = upload(&b->d_chunks, chunks)) != PSA_OK) return fail(st);
+  b->nchunks = (int)chunks.size();
+  if (b->nchunks > 0) {
+    if (hipMalloc((void **)&b->d_chunk_best, chunks.size() * sizeof(unsigned long long)) != hipSuccess) {
       g_err = "hipMalloc(chunk_best) failed";
       return fail(PSA_ERR_HIP);
     }
-    b->nchunks[k] = (int)chunks[k].size();
-    b->grid[k] = std::min(b->nchunks[k], resident[k]);
+    // slabs of the context: grown when this batch needs more, two once a batch needs two passes
+    const int want = b->passes.size() > 1 ? 2 : 1;
+    if (cap_units > c->slab_units || want > c->slab_count) {
+      const size_t units = std::max(cap_units, c->slab_units);
+      const int count = std::max(want, c->slab_count);
+      for (int i = 0; i < 2; ++i) {
+        if (c->d_slab[i]) (void)hipFree(c->d_slab[i]);
+        c->d_slab[i] = nullptr;
+      }
+      c->slab_units = 0;
+      c->slab_count = 0;
+      for (int i = 0; i < count; ++i) {
+        // one extra run: the candidate loop's look-ahead reads 16 values past the last row
+        if (hipMalloc((void **)&c->d_slab[i], (units + 1) * kSlabUnit) != hipSuccess) {
+          g_err = "hipMalloc(enumeration slab) failed";
+          return fail(PSA_ERR_HIP);
+        }
+        if (hipMemset(c->d_slab[i], 0, (units + 1) * kSlabUnit) != hipSuccess) {
+          g_err = "hipMemset(enumeration slab) failed";
+          return fail(PSA_ERR_HIP);
+        }
+      }
+      c->slab_units = units;
+      c->slab_count = count;
+    }
   }
 #define PSA_HIP_B(call)                                               \
   do {                                                                \
@@ -344,15 +448,15 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     PSA_HIP_B(hipMemcpy(b->d_out, b->tmpl.data(), (size_t)n * sizeof(psa_result), hipMemcpyHostToDevice));
     std::memcpy(b->h_out, b->tmpl.data(), (size_t)n * sizeof(psa_result));
   }
-  PSA_HIP_B(hipMalloc((void **)&b->d_counters, (psa::kEnumClasses + 1) * sizeof(unsigned)));
+  PSA_HIP_B(hipMalloc((void **)&b->d_counters, sizeof(unsigned)));
   if (fs_total > 0) {
     PSA_HIP_B(hipMalloc((void **)&b->d_fs, (size_t)fs_total * sizeof(float)));
     PSA_HIP_B(hipMalloc((void **)&b->d_active, (size_t)fs_total * sizeof(psa::ActiveOffset)));
   }
   for (hipEvent_t *e : {&b->ev_first, &b->ev_last, &b->ev_init, &b->ev_res}) PSA_HIP_B(hipEventCreate(e));
-  for (int k = 0; k < psa::kEnumClasses; ++k) {
-    PSA_HIP_B(hipEventCreate(&b->ev_b[k]));
-    PSA_HIP_B(hipEventCreate(&b->ev_e[k]));
+  for (psa_batch::SlabPass &sp : b->passes) {
+    PSA_HIP_B(hipEventCreate(&sp.ev_b));
+    PSA_HIP_B(hipEventCreate(&sp.ev_e));
   }
 #undef PSA_HIP_B
   *out = b;
@@ -375,30 +479,68 @@ int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
 // Enqueues one run on the two streams of the context: accumulator set-up, then the
 // enumeration kernels on st_enum and the resolve kernels on st_res side by side, then
 // the result records and their copy to pinned host memory.  No host synchronisation.
-static int enqueue_run(psa_batch *b, uint32_t stages, bool timed[psa::kEnumClasses]) {
+static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   psa_ctx *c = b->ctx;
   const bool resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
   PSA_HIP(hipEventRecord(b->ev_first, c->st_enum));
-  PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, psa::kEnumClasses + 1, c->st_enum));
+  PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, 1, c->st_enum));
   PSA_HIP(hipEventRecord(b->ev_init, c->st_enum));
   PSA_HIP(psa::debug_sync("psa_init_acc"));
-  if (stages & PSA_STAGE_ENUMERATE) {
-    for (int k = 0; k < psa::kEnumClasses; ++k) {
-      if (b->nchunks[k] == 0) continue;
-      psa::EnumParams P{};
-      P.seq1 = c->d_seq1;
-      P.len1 = c->len1;
-      P.seq2_pool = b->d_pool;
-      P.desc = b->d_desc;
-      P.chunks = b->d_chunks[k];
-      P.chunk_best = b->d_chunk_best[k];
-      P.nchunks = b->nchunks[k];
-      P.counter = b->d_counters + k;
-      P.acc = b->d_acc;
-      P.table_t = c->d_table_t;
-      PSA_HIP(psa::launch_enum(k, P, b->grid[k], b->grid[k], c->st_enum, b->ev_b[k], b->ev_e[k]));
-      timed[k] = true;
+  *timed = false;
+  if ((stages & PSA_STAGE_ENUMERATE) && b->nchunks > 0) {
+    psa::EnumParams P{};
+    P.seq1 = c->d_seq1;
+    P.len1 = c->len1;
+    P.seq2_pool = b->d_pool;
+    P.desc = b->d_desc;
+    P.acc = b->d_acc;
+    P.table_t = c->d_table_t;
+    // One pass: pre-pass and candidate loop follow each other on st_enum.  Several: the
+    // pre-pass of pass k runs on st_pre into slab k % 2 while the candidate loop of pass
+    // k - 1 reads the other slab; it waits for the candidate loop of pass k - 2 to let go.
+    const bool piped = b->passes.size() > 1;
+    hipStream_t sp_stream = piped ? c->st_pre : c->st_enum;
+    if (piped) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
+    for (size_t k = 0; k < b->passes.size(); ++k) {
+      psa_batch::SlabPass &sp = b->passes[k];
+      const int buf = piped ? (int)(k & 1) : 0;
+      if (piped && k >= 2) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->passes[k - 2].ev_e, 0));
+      for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
+        const int c0 = sp.cls_c0[cls + 1], c1 = sp.cls_c0[cls];
+        if (c1 <= c0) continue;
+        P.chunks = b->d_chunks + c0;
+        P.chunk_best = b->d_chunk_best + c0;
+        P.nchunks = c1 - c0;
+        P.fg = c->d_slab[buf];
+        PSA_HIP(psa::launch_enum_prep(cls, P, sp_stream));
+      }
+      if (piped) {
+        PSA_HIP(hipEventRecord(c->ev_prep[buf], c->st_pre));
+        PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[buf], 0));
+      }
+      psa::WaveParams W = sp.wave;
+      W.chunks = b->d_chunks + sp.c0;
+      W.chunk_best = b->d_chunk_best + sp.c0;
+      W.desc = b->d_desc;
+      W.acc = b->d_acc;
+      // while other kernels run beside this one, 41 KB of LDS per workgroup (untouched) keep it
+      // to three workgroups of 8 waves per CU
+      int lds = (resolve || piped) ? 41 * 1024 : 0;
+      if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
+      PSA_HIP(hipEventRecord(sp.ev_b, c->st_enum));
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, lds, c->st_enum));
+      PSA_HIP(hipEventRecord(sp.ev_e, c->st_enum));
     }
+    for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
+      const int c0 = b->cls_c0[cls + 1], c1 = b->cls_c0[cls];
+      if (c1 <= c0) continue;
+      P.chunks = b->d_chunks + c0;
+      P.chunk_best = b->d_chunk_best + c0;
+      P.nchunks = c1 - c0;
+      P.fg = nullptr;
+      PSA_HIP(psa::launch_enum_locate(cls, P, std::min(c1 - c0, 4 * c->num_cus), c->st_enum));
+    }
+    *timed = true;
   }
   if (resolve) {
     PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
@@ -412,7 +554,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool timed[psa::kEnumClass
     P.table_t = c->d_table_t;
     P.fs = b->d_fs;
     P.active = b->d_active;
-    P.nactive = b->d_counters + psa::kEnumClasses;
+    P.nactive = b->d_counters;
     P.pchunks = (b->max_len2 + 255) / 256;
     int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
     PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res));
@@ -459,14 +601,13 @@ int psa_batch_run(psa_batch *b, uint32_t stages) {
         b->graph_exec = nullptr;
       }
       hipGraph_t graph = nullptr;
-      bool timed_dummy[psa::kEnumClasses] = {};
+      bool timed_dummy = false;
       hipError_t e = hipStreamBeginCapture(c->st_enum, hipStreamCaptureModeRelaxed);
-      int st = e == hipSuccess ? enqueue_run(b, stages, timed_dummy) : PSA_ERR_HIP;
+      int st = e == hipSuccess ? enqueue_run(b, stages, &timed_dummy) : PSA_ERR_HIP;
       hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(c->st_enum, &graph) : e;
       if (st == PSA_OK && e2 == hipSuccess && graph &&
           hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
         b->graph_stages = stages;
-        for (int k = 0; k < psa::kEnumClasses; ++k) b->graph_timed[k] = timed_dummy[k];
       } else {
         b->graph_failed = true;  // fall back to kernel-by-kernel launches for this batch
         b->graph_exec = nullptr;
@@ -479,22 +620,21 @@ int psa_batch_run(psa_batch *b, uint32_t stages) {
       launched = true;
     }
   }
-  bool timed[psa::kEnumClasses] = {};
-  if (launched) {
-    for (int k = 0; k < psa::kEnumClasses; ++k) timed[k] = b->graph_timed[k];
-  } else {
-    int st = enqueue_run(b, stages, timed);
+  bool timed = false;  // events recorded inside a replayed graph carry no times
+  if (!launched) {
+    int st = enqueue_run(b, stages, &timed);
     if (st != PSA_OK) return st;
   }
   b->last_stages = stages;
   PSA_HIP(hipStreamSynchronize(c->st_enum));
   PSA_HIP(hipStreamSynchronize(c->st_res));
   b->enum_ms = 0.f;
-  for (int k = 0; k < psa::kEnumClasses; ++k) {
-    if (!timed[k]) continue;
-    float ms = 0.f;
-    PSA_HIP(hipEventElapsedTime(&ms, b->ev_b[k], b->ev_e[k]));
-    b->enum_ms += ms;
+  if (timed) {
+    for (psa_batch::SlabPass &sp : b->passes) {
+      float ms = 0.f;
+      PSA_HIP(hipEventElapsedTime(&ms, sp.ev_b, sp.ev_e));
+      b->enum_ms += ms;
+    }
   }
   PSA_HIP(hipEventElapsedTime(&b->total_ms, b->ev_first, b->ev_last));
   b->ran = true;

@@ -53,7 +53,7 @@ __device__ __forceinline__ Chunk load_chunk(const Chunk *p) {
   c.seq = uni(p->seq);
   c.s0 = uni(p->s0);
   c.ns = uni(p->ns);
-  c.pad = 0;
+  c.fg_row = (uint32_t)uni((int)p->fg_row);
   return c;
 }
 __device__ __forceinline__ SeqDesc load_desc(const SeqDesc *p) {
@@ -64,7 +64,7 @@ __device__ __forceinline__ SeqDesc load_desc(const SeqDesc *p) {
   d.s_begin = uni(p->s_begin);
   d.s_end = uni(p->s_end);
   d.frac_bits = uni(p->frac_bits);
-  d.pad = 0;
+  d.enum_ns = uni(p->enum_ns);
   return d;
 }
 

@@ -10,9 +10,18 @@
 // entries along diagonal delta,
 //   score = f_s[p] + g_s[q],  f_s[p] = E^s[p] - E^{s-1}[p+1],
 //                             g_s[q] = E^{s-1}[q] + E^{s-2}[L2] - E^{s-2}[q+1],
-// so every (s,p,q) costs one integer add and one max.  A workgroup owns a run of
-// offsets; each lane keeps f for R values of p in registers with one running maximum
-// each, g is broadcast from LDS.
+// so every (s,p,q) costs one integer add and one max.
+//
+// Three kernels:
+//   psa_enum_prep    one workgroup per chunk of offsets: prefix sums of the diagonals in
+//                    LDS, then one row of f and one row of g per offset into a slab in HBM
+//                    (8 bytes per position and offset, against L2/2 candidates each);
+//   psa_enum_wave    the candidate loop.  One wave per (offsets, 256 positions p): f sits
+//                    in 4 vector registers per lane, g arrives through scalar loads and is
+//                    used straight from scalar registers; no LDS, no barriers, so waves
+//                    are scheduled one by one and the chip stays full to the last unit;
+//   psa_enum_locate  second pass over the few chunks that hold the maximum: smallest q
+//                    and offset for the winning p.
 //
 // Instruction mix (measured on MI355X): v_add_u32 issues at full rate, every integer
 // or float min/max at half rate, so two candidates are folded into one v_max3_i32:
@@ -27,12 +36,10 @@ struct EnumLds {
   static constexpr int NW = NT / 64;
   // byte offsets inside dynamic LDS
   static constexpr int ring = 0;                     // 3 * NP int32: E^delta for delta mod 3
-  static constexpr int g = ring + 3 * NP * 4;        // NP int32 (+ 4 of slack read by the prefetch)
-  static constexpr int itab = g + NP * 4 + 16;       // kDevTable int32
+  static constexpr int itab = ring + 3 * NP * 4;     // kDevTable int32
   static constexpr int wtot = itab + kDevTable * 4;  // 16 int32
   static constexpr int red = wtot + 16 * 4;          // 16 u64
-  static constexpr int misc = red + 16 * 8;          // 4 int32
-  static constexpr int awin = misc + 16;             // kEnumMaxNs + NP + 2 bytes, rounded up
+  static constexpr int awin = red + 16 * 8;          // kEnumMaxNs + NP + 2 bytes, rounded up
   static constexpr int total = awin + ((kEnumMaxNs + NP + 2 + 15) / 16) * 16;
 };
 
@@ -79,74 +86,6 @@ __device__ __forceinline__ const int *ring_slot(const unsigned char *smem, int d
   return (const int *)(smem + EnumLds<NT, R>::ring) + slot * EnumLds<NT, R>::NP;
 }
 
-__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-
-// q in [qa, qb) (multiples of 4) against registers 0..K-1, every lane valid:
-// the p run of each of those registers lies wholly below qa.
-template <int R, int K>
-__device__ __forceinline__ void enum_full(const int *gL, int qa, int qb, const int (&f)[R], int (&acc)[R]) {
-  if (qa >= qb) return;
-  const int4 *g4 = (const int4 *)(gL + qa);
-  const int n = (qb - qa) >> 2;
-  int4 cur = g4[0];
-#pragma unroll 2
-  for (int u = 0; u < n; ++u) {
-    const int4 nxt = g4[u + 1];  // one group ahead; the last read lands in the slack after g
-    // two passes over the registers, so that consecutive max3 instructions never
-    // update the same accumulator (a dependent pair would stall the issue)
-#pragma unroll
-    for (int r = 0; r < K; ++r) acc[r] = max3i(acc[r], f[r] + cur.x, f[r] + cur.y);
-#pragma unroll
-    for (int r = 0; r < K; ++r) acc[r] = max3i(acc[r], f[r] + cur.z, f[r] + cur.w);
-    cur = nxt;
-  }
-}
-
-template <int NW, int R, int K>
-struct FullPhases {
-  // registers 0..K-1 are complete for q runs qc in (pc(K-1), pc(K)], pc(r) = r*NW + w
-  __device__ static __forceinline__ void run(const int *gL, int w, int qend, const int (&f)[R], int (&acc)[R]) {
-    FullPhases<NW, R, K - 1>::run(gL, w, qend, f, acc);
-    const int qa = 64 * ((K - 1) * NW + w + 1);
-    int qb = (K < R) ? 64 * (K * NW + w + 1) : qend;
-    qb = qb < qend ? qb : qend;
-    enum_full<R, K>(gL, qa, qb, f, acc);
-  }
-};
-template <int NW, int R>
-struct FullPhases<NW, R, 0> {
-  __device__ static __forceinline__ void run(const int *, int, int, const int (&)[R], int (&)[R]) {}
-};
-
-// The q run that coincides with a register's own p run: lane l holds p = q0 + l, so
-// q0 + i pairs only with lanes l < i.  All R registers share the lane mask of step i,
-// so their diagonal runs are walked together under one exec mask per step.
-template <int NW, int R>
-__device__ __forceinline__ void enum_diag(const int *gL, int w, int lane, const int (&f)[R], int (&acc)[R]) {
-#pragma unroll 1
-  for (int i = 0; i < 64; i += 4) {
-    int4 gv[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) gv[r] = *(const int4 *)(gL + 64 * (r * NW + w) + i);
-    if (lane < i) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = max(acc[r], f[r] + gv[r].x);
-    }
-    if (lane < i + 1) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = max(acc[r], f[r] + gv[r].y);
-    }
-    if (lane < i + 2) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = max(acc[r], f[r] + gv[r].z);
-    }
-    if (lane < i + 3) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = max(acc[r], f[r] + gv[r].w);
-    }
-  }
-}
-
 // Shared set-up of a chunk: fixed-point table, Seq2 codes of this thread's
 // positions, Seq1 window, and the two diagonals older than the first offset.
 template <int NT, int R>
@@ -174,82 +113,218 @@ __device__ __forceinline__ void enum_chunk_setup(unsigned char *smem, const Enum
   scan_diagonal<NT, R>(smem, bro, ch.s0 - 1, win0);
 }
 
-// waves per SIMD the register budget is sized for: 8 (at most 64 VGPRs) except for the
-// largest variant, whose 32 running maxima and f values per lane need 128
-constexpr int enum_waves_per_simd(int nt, int r) { return nt * r > 4096 ? 4 : 8; }
-
+// ---- pre-pass -----------------------------------------------------------------------
+// Row of offset s in the slab: 64*nruns f values (0 beyond p = L2-2), then 64*nruns g
+// values (q = 0 repeats g[1], q >= L2 repeat g[L2-1]: duplicates of scored candidates).
 template <int NT, int R>
-__global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_main(EnumParams P) {
-  using L = EnumLds<NT, R>;
-  constexpr int NW = NT / 64;
+__global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
-  int *gL = (int *)(smem + L::g);
-  int *misc = (int *)(smem + L::misc);
-  unsigned long long *red = (unsigned long long *)(smem + L::red);
-
-  // Every branch that encloses a barrier tests a scalar (readfirstlane) value, so
-  // the compiler keeps the loop wave-uniform and all lanes reach each barrier together.
-  if (tid == 0) misc[0] = (int)atomicAdd(P.counter, 1u);
-  __syncthreads();
-  int c = uni(misc[0]);
-  while (c < P.nchunks) {
-    const Chunk ch = load_chunk(P.chunks + c);
-    const SeqDesc d = load_desc(P.desc + ch.seq);
-    const int L2 = d.len2;
-    int bro[R];
-    int win0;
-    enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
-
-    int acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = INT_MIN;
-    const int qend = 64 * ((L2 - 1) / 64 + 1);  // q runs cover 1 .. L2-1, padded to whole runs
-
-    for (int s = ch.s0; s < ch.s0 + ch.ns; ++s) {
-      scan_diagonal<NT, R>(smem, bro, s, win0);
-      const int *Es = ring_slot<NT, R>(smem, s);
-      const int *E1 = ring_slot<NT, R>(smem, s - 1);
-      const int *E2 = ring_slot<NT, R>(smem, s - 2);
-      const int tot2 = E2[L2];
-      int f[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int p = r * NT + tid;
-        f[r] = (p <= L2 - 2) ? Es[p] - E1[p + 1] : 0;
-        int qq = p < 1 ? 1 : (p > L2 - 1 ? L2 - 1 : p);  // positions past the end repeat g[L2-1]
-        gL[p] = E1[qq] + tot2 - E2[qq + 1];
-      }
-      __syncthreads();
-      FullPhases<NW, R, R>::run(gL, w, qend, f, acc);
-      enum_diag<NW, R>(gL, w, lane, f, acc);
-    }
-
-    // best fixed-point score of this chunk and the smallest p attaining it
-    int bestv = INT_MIN;
-    uint32_t bestp = 0x7fffffffu;
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x;
+  const Chunk ch = load_chunk(P.chunks + c);
+  const SeqDesc d = load_desc(P.desc + ch.seq);
+  const int L2 = d.len2;
+  const int npos = 64 * ((L2 + 63) >> 6);
+  if (tid == 0) P.chunk_best[c] = 0ull;
+  int bro[R];
+  int win0;
+  enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
+  int *row = P.fg + (size_t)ch.fg_row * 64;
+  for (int s = ch.s0; s < ch.s0 + ch.ns; ++s) {
+    // the slot this scan overwrites (diagonal s-3) was last read before the scan's first barrier
+    scan_diagonal<NT, R>(smem, bro, s, win0);
+    const int *Es = ring_slot<NT, R>(smem, s);
+    const int *E1 = ring_slot<NT, R>(smem, s - 1);
+    const int *E2 = ring_slot<NT, R>(smem, s - 2);
+    const int tot2 = E2[L2];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int p = r * NT + tid;
-      if (p <= L2 - 2 && acc[r] > bestv) {
-        bestv = acc[r];
-        bestp = (uint32_t)p;
+      if (p < npos) {
+        const int qq = p < 1 ? 1 : (p > L2 - 1 ? L2 - 1 : p);
+        row[p] = (p <= L2 - 2) ? Es[p] - E1[p + 1] : 0;
+        row[npos + p] = E1[qq] + tot2 - E2[qq + 1];
       }
     }
-    unsigned long long key = ((unsigned long long)((uint32_t)bestv ^ 0x80000000u) << 32) | (0xffffffffu - bestp);
-    key = wave_max_u64(key);
-    if (lane == 0) red[w] = key;
-    __syncthreads();
-    if (tid == 0) {
-      for (int i = 1; i < NW; ++i) key = red[i] > key ? red[i] : key;
-      P.chunk_best[c] = key;  // lets the second pass skip chunks that cannot hold the winner
-      atomicMax(&P.acc[ch.seq].enum_key, key);
-      misc[0] = (int)atomicAdd(P.counter, 1u);  // next chunk
-    }
-    __syncthreads();
-    c = uni(misc[0]);
+    row += 2 * npos + 64;  // one run of padding: rows must not start a power of two apart
   }
 }
+
+// ---- candidate loop -----------------------------------------------------------------
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// The two instructions of the candidate loop, pinned: hipcc orders volatile asm
+// statements as written, and the order decides the speed here (see wave_full).
+__device__ __forceinline__ int add_sv(int g, int f) {
+  int t;
+  asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "s"(g), "v"(f));
+  return t;
+}
+__device__ __forceinline__ void max3_acc(int &a, int x, int y) {
+  asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+}
+
+// q in [qa, qb) (multiples of 64) against registers 0..K-1, every lane valid.  G is
+// wave-uniform, so the 16 values of a step come in with one scalar load and feed
+// v_add_u32 as scalar operands; the other waves of the SIMD cover the load's latency.
+// A step is four blocks of 4 g values; the sums of a block are consumed by v_max3_i32
+// two blocks later (A0 A1 M0 A2 M1 A3 M2 M3).  Left to itself hipcc sometimes emits
+// add, add, max3 on two temporaries, where every max3 waits for the adds right before
+// it: 15 % slower.  Two accumulators per register keep consecutive max3 on different
+// registers.
+template <int R, int K>
+__device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int qb, const int (&f)[R],
+                                          int (&acc)[R][2]) {
+  for (int q = qa; q < qb; q += 16) {
+    int g[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] = G[q + i];
+    int t[4][K][4];
+    auto sums = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][0] = add_sv(g[4 * b], f[r]);
+        t[b][r][1] = add_sv(g[4 * b + 1], f[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][2] = add_sv(g[4 * b + 2], f[r]);
+        t[b][r][3] = add_sv(g[4 * b + 3], f[r]);
+      }
+    };
+    auto maxima = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) max3_acc(acc[r][0], t[b][r][0], t[b][r][1]);
+#pragma unroll
+      for (int r = 0; r < K; ++r) max3_acc(acc[r][1], t[b][r][2], t[b][r][3]);
+    };
+    sums(0);
+    sums(1);
+    maxima(0);
+    sums(2);
+    maxima(1);
+    sums(3);
+    maxima(2);
+    maxima(3);
+  }
+}
+
+// Register r holds run pc0 + r.  The q run pc0 + K pairs with registers 0..K-1 only
+// (K < R); everything from run pc0 + R on pairs with all R registers.
+template <int R, int K>
+struct WavePhases {
+  __device__ static __forceinline__ void run(const int *__restrict__ G, int pc0, int qend, const int (&f)[R],
+                                             int (&acc)[R][2]) {
+    WavePhases<R, K - 1>::run(G, pc0, qend, f, acc);
+    const int qa = 64 * (pc0 + K);
+    const int qb = (K < R) ? min(qa + 64, qend) : qend;
+    wave_full<R, K>(G, qa, qb, f, acc);
+  }
+};
+template <int R>
+struct WavePhases<R, 0> {
+  __device__ static __forceinline__ void run(const int *__restrict__, int, int, const int (&)[R], int (&)[R][2]) {}
+};
+
+// The q run that coincides with a register's own p run: lane l holds p = q0 + l, so
+// q0 + i pairs only with lanes l < i.  All R registers share the lane mask of step i.
+template <int R>
+__device__ __forceinline__ void wave_diag(const int *__restrict__ G, int pc0, int nruns, int lane, const int (&f)[R],
+                                          int (&acc)[R][2]) {
+#pragma unroll 1
+  for (int i0 = 0; i0 < 64; i0 += 8) {
+    int g[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int base = pc0 + r < nruns ? 64 * (pc0 + r) + i0 : 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[r][i] = G[base + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (lane < i0 + i) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][i & 1] = max(acc[r][i & 1], f[r] + g[r][i]);
+      }
+    }
+  }
+}
+
+// One unit: sub-run j of chunk c at level w (positions p in [256 w, 256 w + 256)).
+template <int R>
+__device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const WaveParams &P, int u, int lane) {
+  int w = 0;
+#pragma unroll
+  for (int i = 1; i < kEnumMaxLevels; ++i) w += (u >= P.level_base[i]) ? 1 : 0;
+  const int m = u - P.level_base[w];
+  const int c = m >> P.sub_log2, j = m & ((1 << P.sub_log2) - 1);
+  const Chunk ch = load_chunk(P.chunks + c);
+  const SeqDesc d = load_desc(P.desc + ch.seq);
+  const int r0 = j * d.enum_ns;
+  if (r0 >= ch.ns) return;
+  const int r1 = min(r0 + d.enum_ns, ch.ns);
+  const int L2 = d.len2;
+  const int nruns = (L2 + 63) >> 6;
+  const int qend = 64 * nruns;
+  const int pc0 = w * R;
+  const int *__restrict__ F = fg + ((size_t)ch.fg_row + (size_t)r0 * (2 * nruns + 1)) * 64;
+  int fn[R], acc[R][2];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
+    acc[r][0] = acc[r][1] = INT_MIN;
+  }
+  for (int i = r0; i < r1; ++i) {
+    int f[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) f[r] = fn[r];
+    const int *__restrict__ G = F + qend;
+    F += 2 * qend + 64;
+    if (i + 1 < r1) {  // next offset's f values arrive while this one is scored
+#pragma unroll
+      for (int r = 0; r < R; ++r) fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
+    }
+    WavePhases<R, R>::run(G, pc0, qend, f, acc);
+    wave_diag<R>(G, pc0, nruns, lane, f, acc);
+  }
+  // best fixed-point score of this unit and the smallest p attaining it
+  int bestv = INT_MIN;
+  uint32_t bestp = 0x7fffffffu;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int p = 64 * (pc0 + r) + lane;
+    const int a = max(acc[r][0], acc[r][1]);
+    if (p <= L2 - 2 && a > bestv) {
+      bestv = a;
+      bestp = (uint32_t)p;
+    }
+  }
+  unsigned long long key = ((unsigned long long)((uint32_t)bestv ^ 0x80000000u) << 32) | (0xffffffffu - bestp);
+  key = wave_max_u64(key);
+  if (lane == 0) {
+    // a stale read can only be too small, which costs an atomic, never a result
+    if (key > P.chunk_best[c]) atomicMax(&P.chunk_best[c], key);  // lets the locate pass skip chunks
+    if (key > P.acc[ch.seq].enum_key) atomicMax(&P.acc[ch.seq].enum_key, key);
+  }
+}
+
+// A workgroup is 8 independent waves, each scoring one unit: no barrier, no LDS traffic.
+// Workgroups are launched in unit order and the SIMD issues its oldest wave first, so units
+// finish roughly in the order they were numbered (largest first) and the last waves of a
+// launch are short ones.  (Resident waves that draw unit numbers from a counter were
+// measured 25 % slower: the issue order starves the youngest waves of each SIMD, which
+// then hold their first, largest units until every other wave has run out of work.)
+// The launch may ask for LDS it never uses: 41 KB pins three workgroups per CU, which
+// leaves wave slots, registers and LDS for the short kernels of the other streams.
+template <int R>
+__global__ __launch_bounds__(512, 8) void psa_enum_wave(const int *__restrict__ fg, WaveParams P) {
+  const int lane = threadIdx.x & 63;
+  const int u = uni((int)(blockIdx.x * 8 + (threadIdx.x >> 6)));
+  if (u < P.nunits) wave_unit<R>(fg, P, u, lane);
+}
+
+// waves per SIMD the locate kernel's register budget is sized for
+constexpr int enum_waves_per_simd(int nt, int r) { return nt * r > 4096 ? 4 : 8; }
 
 // Second pass: knowing the maximum G and the smallest p* that attains it, find the
 // smallest q and then the smallest offset with f_s[p*] + g_s[q] == G.  Only chunks
@@ -306,27 +381,43 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
 }
 
 template <int NT, int R>
-static hipError_t launch_enum_t(const EnumParams &P, int grid_main, int grid_locate, hipStream_t st,
-                                hipEvent_t ev_begin, hipEvent_t ev_end) {
+static hipError_t set_lds_attr() {
   using L = EnumLds<NT, R>;
   static bool attr_done = false;
-  hipError_t e;
-  if (!attr_done) {
-    e = hipFuncSetAttribute((const void *)psa_enum_main<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)psa_enum_locate<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            L::total);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  if (ev_begin && (e = hipEventRecord(ev_begin, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL((psa_enum_main<NT, R>), dim3(grid_main), dim3(NT), L::total, st, P);
+  if (attr_done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     L::total);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)psa_enum_locate<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+  if (e != hipSuccess) return e;
+  attr_done = true;
+  return hipSuccess;
+}
+
+template <int NT, int R>
+static hipError_t launch_prep_t(const EnumParams &P, hipStream_t st) {
+  hipError_t e = set_lds_attr<NT, R>();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((psa_enum_prep<NT, R>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (ev_end && (e = hipEventRecord(ev_end, st)) != hipSuccess) return e;
-  if ((e = debug_sync("psa_enum_main")) != hipSuccess) return e;
-  hipLaunchKernelGGL((psa_enum_locate<NT, R>), dim3(grid_locate), dim3(NT), L::total, st, P);
+  return debug_sync("psa_enum_prep");
+}
+
+template <int NT, int R>
+static hipError_t launch_locate_t(const EnumParams &P, int grid, hipStream_t st) {
+  hipError_t e = set_lds_attr<NT, R>();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((psa_enum_locate<NT, R>), dim3(grid), dim3(NT), (EnumLds<NT, R>::total), st, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_enum_locate");
+}
+
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, int lds_bytes, hipStream_t st) {
+  if (P.nunits <= 0) return hipSuccess;
+  hipLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st, fg, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return debug_sync("psa_enum_wave");
 }
 
 int enum_class_of(int len2) {
@@ -353,15 +444,28 @@ int enum_class_lds_bytes(int c) {
 
 int enum_class_threads(int c) { return c < 2 ? 256 : (c < 4 ? 512 : 1024); }
 
-hipError_t launch_enum(int cls, const EnumParams &P, int grid_main, int grid_locate, hipStream_t st,
-                       hipEvent_t ev_begin, hipEvent_t ev_end) {
+hipError_t launch_enum_prep(int cls, const EnumParams &P, hipStream_t st) {
+  if (P.nchunks <= 0) return hipSuccess;
   switch (cls) {
-    case 0: return launch_enum_t<256, 1>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 1: return launch_enum_t<256, 2>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 2: return launch_enum_t<512, 2>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 3: return launch_enum_t<512, 4>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 4: return launch_enum_t<1024, 4>(P, grid_main, grid_locate, st, ev_begin, ev_end);
-    case 5: return launch_enum_t<1024, 8>(P, grid_main, grid_locate, st, ev_begin, ev_end);
+    case 0: return launch_prep_t<256, 1>(P, st);
+    case 1: return launch_prep_t<256, 2>(P, st);
+    case 2: return launch_prep_t<512, 2>(P, st);
+    case 3: return launch_prep_t<512, 4>(P, st);
+    case 4: return launch_prep_t<1024, 4>(P, st);
+    case 5: return launch_prep_t<1024, 8>(P, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st) {
+  if (P.nchunks <= 0) return hipSuccess;
+  switch (cls) {
+    case 0: return launch_locate_t<256, 1>(P, grid, st);
+    case 1: return launch_locate_t<256, 2>(P, grid, st);
+    case 2: return launch_locate_t<512, 2>(P, grid, st);
+    case 3: return launch_locate_t<512, 4>(P, grid, st);
+    case 4: return launch_locate_t<1024, 4>(P, grid, st);
+    case 5: return launch_locate_t<1024, 8>(P, grid, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -24,7 +24,7 @@ struct SeqDesc {
   int32_t s_begin;    // offsets [s_begin, s_end) are scored
   int32_t s_end;
   int32_t frac_bits;  // fixed-point scale of the enumeration stage, -1 = stage off for this Seq2
-  int32_t pad;
+  int32_t enum_ns;    // offsets one wave of the enumeration kernel walks (a sub-run of a chunk)
 };
 
 // Per-Seq2 accumulators the kernels reduce into with 64/32-bit atomics.
@@ -36,12 +36,13 @@ struct SeqAcc {
   int32_t res_p;                // min p attaining the float32 maximum
 };
 
-// A unit of enumeration work: ns consecutive offsets of one Seq2.
+// ns consecutive offsets of one Seq2: the unit of the enumeration pre-pass, which writes
+// the f and g values of those offsets as rows of the slab starting at fg_row.
 struct Chunk {
   int32_t seq;
   int32_t s0;
   int32_t ns;
-  int32_t pad;
+  uint32_t fg_row;  // first row of the chunk in the slab, in units of 64 int32
 };
 
 // A block of up to 256 consecutive offsets of one Seq2 for the forward recurrence.

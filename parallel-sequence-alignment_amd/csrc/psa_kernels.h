@@ -8,20 +8,37 @@
 
 namespace psa {
 
-constexpr int kEnumMaxNs = 64;   // most offsets in one enumeration chunk
-constexpr int kEnumClasses = 6;  // (threads, registers) variants of the enumeration kernels
+constexpr int kEnumMaxNs = 64;      // most offsets in one enumeration chunk
+constexpr int kEnumClasses = 6;     // (threads, registers) variants of the pre-pass and locate kernels
+constexpr int kEnumWaveRuns = 4;    // runs of 64 positions p one wave of psa_enum_wave keeps in registers
+constexpr int kEnumMaxLevels = 32;  // ceil(ceil(PSA_MAX_SEQ2 / 64) / kEnumWaveRuns)
 
+// Pre-pass and locate kernels: one workgroup per chunk.
 struct EnumParams {
   const unsigned char *seq1;       // residue codes 0..25
   int64_t len1;
   const unsigned char *seq2_pool;  // residue codes of every Seq2 of the batch
   const SeqDesc *desc;
-  const Chunk *chunks;             // chunks of this kernel class
+  const Chunk *chunks;             // chunks of this launch
   int nchunks;
-  unsigned *counter;               // work counter of this class (zeroed by psa_init_acc)
   SeqAcc *acc;
   const float *table_t;            // float table [seq2 code][seq1 code], stride 32, 27 rows
-  unsigned long long *chunk_best;  // per chunk: its (maximum, smallest p) key, written by psa_enum_main
+  unsigned long long *chunk_best;  // per chunk: max of its waves' (maximum, smallest p) keys
+  int *fg;                         // slab the pre-pass writes: per offset 64*nruns f values, then 64*nruns g values
+};
+
+// psa_enum_wave: one unit of work per (chunk, sub-run of its offsets, level).  Level w owns the
+// positions p in [256 w, 256 w + 256); chunks are sorted by falling Seq2 length, so the
+// chunks that have a level w are a prefix of the launch's chunk list and the units are
+// numbered level by level: unit u of level w is sub-run (u - level_base[w]) of that prefix.
+struct WaveParams {
+  const Chunk *chunks;
+  const SeqDesc *desc;
+  SeqAcc *acc;
+  unsigned long long *chunk_best;
+  int sub_log2;                            // sub-runs per chunk = 1 << sub_log2
+  int level_base[kEnumMaxLevels + 1];      // first unit of each level; unused entries hold INT_MAX
+  int nunits;
 };
 
 struct ResolveParams {
@@ -55,8 +72,9 @@ int enum_class_threads(int c);
 
 hipError_t debug_sync(const char *what);
 hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hipStream_t st);
-hipError_t launch_enum(int cls, const EnumParams &P, int grid_main, int grid_locate, hipStream_t st,
-                       hipEvent_t ev_begin, hipEvent_t ev_end);
+hipError_t launch_enum_prep(int cls, const EnumParams &P, hipStream_t st);
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, int lds_bytes, hipStream_t st);
+hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st);
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st);
 hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st);
 

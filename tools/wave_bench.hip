@@ -1,0 +1,117 @@
+// Times psa_enum_wave of libpsa_hip on a synthetic slab (random f/g rows), without the
+// rest of a run around it.
+// Build: hipcc -O3 --offload-arch=gfx950 -I../include -o wave_bench wave_bench.hip \
+//        -L../parallel-sequence-alignment_amd -lpsa_hip -Wl,-rpath,'$ORIGIN/../parallel-sequence-alignment_amd'
+// Run:   ./wave_bench [offsets] [len2] [enum_ns] [sub_log2] [reps] [lds_bytes]
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../parallel-sequence-alignment_amd/csrc/psa_kernels.h"
+
+#define CK(x)                                                      \
+  do {                                                             \
+    hipError_t e_ = (x);                                           \
+    if (e_ != hipSuccess) {                                        \
+      std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); \
+      std::exit(1);                                                \
+    }                                                              \
+  } while (0)
+
+int main(int argc, char **argv) {
+  const int rows = argc > 1 ? std::atoi(argv[1]) : 4012;
+  const int len2 = argc > 2 ? std::atoi(argv[2]) : 2000;
+  const int ens = argc > 3 ? std::atoi(argv[3]) : 1;
+  const int sub_log2 = argc > 4 ? std::atoi(argv[4]) : 3;
+  const int reps = argc > 5 ? std::atoi(argv[5]) : 20;
+  const int lds = argc > 6 ? std::atoi(argv[6]) : 0;
+  const int nruns = (len2 + 63) / 64, stride = 128 * nruns + 64;
+  const int levels = (nruns + psa::kEnumWaveRuns - 1) / psa::kEnumWaveRuns;
+  const int per = std::min(ens << sub_log2, psa::kEnumMaxNs);
+  std::vector<int> h((size_t)rows * stride + 64, 0);
+  uint32_t x = 12345u;
+  auto rnd = [&]() {
+    x = x * 1664525u + 1013904223u;
+    return (int)(x >> 8) % 200000 - 100000;
+  };
+  for (int r = 0; r < rows; ++r) {
+    int *F = h.data() + (size_t)r * stride, *G = F + 64 * nruns;
+    for (int p = 0; p <= len2 - 2; ++p) F[p] = rnd();
+    for (int q = 1; q <= len2 - 1; ++q) G[q] = rnd();
+    G[0] = G[1];
+    for (int q = len2; q < 64 * nruns; ++q) G[q] = G[len2 - 1];
+  }
+  std::vector<psa::Chunk> chunks;
+  for (int s0 = 0; s0 < rows; s0 += per)
+    chunks.push_back(psa::Chunk{0, s0, std::min(per, rows - s0), (uint32_t)((size_t)s0 * (2 * nruns + 1))});
+  psa::SeqDesc d{};
+  d.len2 = len2;
+  d.s_begin = 0;
+  d.s_end = rows;
+  d.frac_bits = 0;
+  d.enum_ns = ens;
+  psa::WaveParams W{};
+  W.sub_log2 = sub_log2;
+  for (int w = 0; w <= psa::kEnumMaxLevels; ++w) W.level_base[w] = INT_MAX;
+  for (int w = 0; w < levels; ++w) W.level_base[w] = w * ((int)chunks.size() << sub_log2);
+  W.nunits = levels * ((int)chunks.size() << sub_log2);
+  int *dfg;
+  psa::Chunk *dch;
+  psa::SeqDesc *dd;
+  psa::SeqAcc *dacc;
+  unsigned long long *dbest;
+  CK(hipMalloc((void **)&dfg, h.size() * 4));
+  CK(hipMemcpy(dfg, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc((void **)&dch, chunks.size() * sizeof(psa::Chunk)));
+  CK(hipMemcpy(dch, chunks.data(), chunks.size() * sizeof(psa::Chunk), hipMemcpyHostToDevice));
+  CK(hipMalloc((void **)&dd, sizeof d));
+  CK(hipMemcpy(dd, &d, sizeof d, hipMemcpyHostToDevice));
+  CK(hipMalloc((void **)&dacc, sizeof(psa::SeqAcc)));
+  CK(hipMemset(dacc, 0, sizeof(psa::SeqAcc)));
+  CK(hipMalloc((void **)&dbest, chunks.size() * 8));
+  CK(hipMemset(dbest, 0, chunks.size() * 8));
+  W.chunks = dch;
+  W.desc = dd;
+  W.acc = dacc;
+  W.chunk_best = dbest;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  CK(psa::launch_enum_wave(dfg, W, lds, st));
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, lds, st));
+  CK(hipEventRecord(b, st));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  ms /= reps;
+  psa::SeqAcc acc;
+  CK(hipMemcpy(&acc, dacc, sizeof acc, hipMemcpyDeviceToHost));
+  // brute-force check of the overall maximum and its smallest p
+  long long bv = LLONG_MIN;
+  int bp = -1;
+  for (int r = 0; r < rows; ++r) {
+    const int *F = h.data() + (size_t)r * stride, *G = F + 64 * nruns;
+    int sm = INT_MIN;  // suffix maximum of g
+    for (int p = len2 - 2; p >= 0; --p) {
+      sm = std::max(sm, G[p + 1]);
+      const long long v = (long long)F[p] + sm;
+      if (v > bv || (v == bv && p < bp)) {
+        bv = v;
+        bp = p;
+      }
+    }
+  }
+  const int gv = (int)((uint32_t)(acc.enum_key >> 32) ^ 0x80000000u), gp = (int)(0xffffffffu - (uint32_t)acc.enum_key);
+  const double cand = (double)rows * ((double)len2 * (len2 - 1) / 2);
+  std::printf("offsets=%d len2=%d enum_ns=%d sub_log2=%d units=%d lds=%d  %.4f ms  %.3e cand/s  frac=%.3f  check=%s\n", rows,
+              len2, ens, sub_log2, W.nunits, lds, ms, cand / (ms * 1e-3), 2 * cand / (ms * 1e-3) / 78.6432e12,
+              (gv == (int)bv && gp == bp) ? "ok" : "FAIL");
+  return !(gv == (int)bv && gp == bp);
+}
