@@ -326,7 +326,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     d.enum_ns = (int32_t)std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
     min_ns = std::min(min_ns, d.enum_ns);
   }
-  int sub_log2 = min_ns >= 8 ? 0 : (min_ns >= 4 ? 1 : (min_ns >= 2 ? 2 : 3));
+  int sub_log2 = min_ns >= 4 ? 0 : (min_ns >= 2 ? 1 : 2);  // chunks of at least 4 offsets
   if (const char *e = std::getenv("PSA_ENUM_SUB_LOG2")) sub_log2 = std::max(0, std::min(3, std::atoi(e)));  // tuning aid
   size_t total_units = 0;
   for (int i : order) {
@@ -542,6 +542,15 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     }
     *timed = true;
   }
+  psa::FinalParams F{};
+  F.seq1 = c->d_seq1;
+  F.seq2_pool = b->d_pool;
+  F.desc = b->d_desc;
+  F.acc = b->d_acc;
+  F.class_t = c->d_class_t;
+  F.out = b->d_out;
+  F.stages = stages;
+  F.which = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   if (resolve) {
     PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
     psa::ResolveParams P{};
@@ -558,19 +567,15 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.pchunks = (b->max_len2 + 255) / 256;
     int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
     PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res));
+    // the float32 half of the records is filled on the resolve stream, beside the enumeration
+    F.which = PSA_STAGE_RESOLVE;
+    PSA_HIP(psa::launch_finalize(F, b->n, c->st_res));
     PSA_HIP(hipEventRecord(b->ev_res, c->st_res));
-    PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_res, 0));
+    F.which = PSA_STAGE_ENUMERATE;
   }
-  psa::FinalParams F{};
-  F.seq1 = c->d_seq1;
-  F.seq2_pool = b->d_pool;
-  F.desc = b->d_desc;
-  F.acc = b->d_acc;
-  F.class_t = c->d_class_t;
-  F.out = b->d_out;
-  F.stages = stages;
   PSA_HIP(psa::launch_finalize(F, b->n, c->st_enum));
   PSA_HIP(psa::debug_sync("psa_finalize"));
+  if (resolve) PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_res, 0));
   PSA_HIP(hipMemcpyAsync(b->h_out, b->d_out, (size_t)b->n * sizeof(psa_result), hipMemcpyDeviceToHost, c->st_enum));
   PSA_HIP(hipEventRecord(b->ev_last, c->st_enum));
   return PSA_OK;

@@ -227,10 +227,16 @@ struct WavePhases<R, 0> {
 };
 
 // The q run that coincides with a register's own p run: lane l holds p = q0 + l, so
-// q0 + i pairs only with lanes l < i.  All R registers share the lane mask of step i.
+// q0 + i pairs only with lanes l < i.  Steps are taken two at a time: for even i the
+// lanes l < i take q0 + i and q0 + i + 1 in one max3; what that leaves out, lane i with
+// q0 + i + 1, is the pair (p, p + 1) of every even lane and is added at the end from a
+// per-lane load.  All R registers share the lane mask of a step.
 template <int R>
 __device__ __forceinline__ void wave_diag(const int *__restrict__ G, int pc0, int nruns, int lane, const int (&f)[R],
                                           int (&acc)[R][2]) {
+  int gnext[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) gnext[r] = G[(pc0 + r < nruns ? 64 * (pc0 + r) : 0) + lane + 1];
 #pragma unroll 1
   for (int i0 = 0; i0 < 64; i0 += 8) {
     int g[R][8];
@@ -241,12 +247,22 @@ __device__ __forceinline__ void wave_diag(const int *__restrict__ G, int pc0, in
       for (int i = 0; i < 8; ++i) g[r][i] = G[base + i];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; i += 2) {
       if (lane < i0 + i) {
+        int t[R][2];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r][i & 1] = max(acc[r][i & 1], f[r] + g[r][i]);
+        for (int r = 0; r < R; ++r) {
+          t[r][0] = add_sv(g[r][i], f[r]);
+          t[r][1] = add_sv(g[r][i + 1], f[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) max3_acc(acc[r][(i >> 1) & 1], t[r][0], t[r][1]);
       }
     }
+  }
+  if ((lane & 1) == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r][0] = max(acc[r][0], f[r] + gnext[r]);
   }
 }
 

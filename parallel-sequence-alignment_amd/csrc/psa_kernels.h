@@ -62,7 +62,8 @@ struct FinalParams {
   const SeqAcc *acc;
   const unsigned char *class_t;  // residue class [seq2 code][seq1 code], stride 32
   psa_result *out;
-  uint32_t stages;
+  uint32_t stages;  // stages of the run
+  uint32_t which;   // PSA_STAGE_* bits: the halves of the records this launch fills
 };
 
 int enum_class_of(int len2);          // -1 if len2 is too long

@@ -381,6 +381,9 @@ __device__ void count_classes(const FinalParams &P, const SeqDesc &d, int s, int
   __syncthreads();
 }
 
+// P.which says which half of the records this launch fills: the float32 (resolve) fields,
+// the fixed-point (enumeration) fields, or both.  The halves are launched on the streams
+// that produce their inputs, so the resolve half is done long before the enumeration ends.
 __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   __shared__ int lds_counts[4];
   const int i = blockIdx.x;
@@ -388,40 +391,44 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   const SeqAcc a = P.acc[i];
   psa_result *r = P.out + i;
   const int tid = threadIdx.x;
-  const bool res_ok = uni((P.stages & PSA_STAGE_RESOLVE) && a.res_loc != ~0ull && a.res_p != INT_MAX);
-  const bool enum_ok = uni((P.stages & PSA_STAGE_ENUMERATE) && d.frac_bits >= 0 && a.enum_loc != ~0ull);
-  if (res_ok) {
-    const int p = a.res_p, q = (int)(a.res_loc >> 32), s = (int)(uint32_t)a.res_loc;
-    count_classes(P, d, s, p, q, lds_counts, r->counts);
-    if (tid == 0) {
-      r->n = p + 1;
-      r->k = q + 1;
-      r->offset = s;
-      const float sc = key2f(a.res_key);
-      r->score = sc;
-      r->score_bits = __float_as_uint(sc);
-      const long long L = d.len2, n = p + 1;
-      r->mutant_num = (int32_t)((n - 1) * L - n * (n - 1) / 2 + (q - p) - 1);
+  if (uni((int)(P.which & PSA_STAGE_RESOLVE))) {
+    const bool res_ok = uni((P.stages & PSA_STAGE_RESOLVE) && a.res_loc != ~0ull && a.res_p != INT_MAX);
+    if (res_ok) {
+      const int p = a.res_p, q = (int)(a.res_loc >> 32), s = (int)(uint32_t)a.res_loc;
+      count_classes(P, d, s, p, q, lds_counts, r->counts);
+      if (tid == 0) {
+        r->n = p + 1;
+        r->k = q + 1;
+        r->offset = s;
+        const float sc = key2f(a.res_key);
+        r->score = sc;
+        r->score_bits = __float_as_uint(sc);
+        const long long L = d.len2, n = p + 1;
+        r->mutant_num = (int32_t)((n - 1) * L - n * (n - 1) / 2 + (q - p) - 1);
+      }
+    } else if (tid == 0) {
+      r->n = r->k = r->offset = r->mutant_num = 0;
+      r->score = 0.0f;
+      r->score_bits = 0u;
+      r->counts[0] = r->counts[1] = r->counts[2] = r->counts[3] = 0;
     }
-  } else if (tid == 0) {
-    r->n = r->k = r->offset = r->mutant_num = 0;
-    r->score = 0.0f;
-    r->score_bits = 0u;
-    r->counts[0] = r->counts[1] = r->counts[2] = r->counts[3] = 0;
   }
-  if (enum_ok) {
-    const int p = (int)(0xffffffffu - (uint32_t)a.enum_key);
-    const int q = (int)(a.enum_loc >> 32), s = (int)(uint32_t)a.enum_loc;
-    count_classes(P, d, s, p, q, lds_counts, r->enum_counts);
-    if (tid == 0) {
-      r->enum_n = p + 1;
-      r->enum_k = q + 1;
-      r->enum_offset = s;
-      r->enum_score = (int)((uint32_t)(a.enum_key >> 32) ^ 0x80000000u);
+  if (uni((int)(P.which & PSA_STAGE_ENUMERATE))) {
+    const bool enum_ok = uni((P.stages & PSA_STAGE_ENUMERATE) && d.frac_bits >= 0 && a.enum_loc != ~0ull);
+    if (enum_ok) {
+      const int p = (int)(0xffffffffu - (uint32_t)a.enum_key);
+      const int q = (int)(a.enum_loc >> 32), s = (int)(uint32_t)a.enum_loc;
+      count_classes(P, d, s, p, q, lds_counts, r->enum_counts);
+      if (tid == 0) {
+        r->enum_n = p + 1;
+        r->enum_k = q + 1;
+        r->enum_offset = s;
+        r->enum_score = (int)((uint32_t)(a.enum_key >> 32) ^ 0x80000000u);
+      }
+    } else if (tid == 0) {
+      r->enum_n = r->enum_k = r->enum_offset = r->enum_score = 0;
+      r->enum_counts[0] = r->enum_counts[1] = r->enum_counts[2] = r->enum_counts[3] = 0;
     }
-  } else if (tid == 0) {
-    r->enum_n = r->enum_k = r->enum_offset = r->enum_score = 0;
-    r->enum_counts[0] = r->enum_counts[1] = r->enum_counts[2] = r->enum_counts[3] = 0;
   }
 }
 
