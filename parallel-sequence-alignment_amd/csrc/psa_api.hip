@@ -73,11 +73,14 @@ struct psa_batch {
   // [c0, c1), whose rows fit one slab
   struct SlabPass {
     int c0 = 0, c1 = 0;
+    int buf = 0;        // slab of the context this pass uses
+    int reuse_of = -1;  // earlier pass whose rows it overwrites (its candidate loop must be done), -1 = none
     int cls_c0[psa::kEnumClasses + 1] = {};  // chunks of kernel class k: [cls_c0[k + 1], cls_c0[k]) (classes fall)
     psa::WaveParams wave{};
     hipEvent_t ev_b = nullptr, ev_e = nullptr;
   };
   std::vector<SlabPass> passes;
+  bool two_slabs = false;
   psa::Chunk *d_chunks = nullptr;
   unsigned long long *d_chunk_best = nullptr;
   int nchunks = 0;
@@ -357,6 +360,12 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       used += need;
     }
     if (!b->passes.empty()) b->passes.back().c1 = (int)chunks.size();
+    bool two_slabs = b->passes.size() > 1;
+    for (size_t k = 0; k < b->passes.size(); ++k) {
+      b->passes[k].buf = (int)(k & 1);
+      b->passes[k].reuse_of = k >= 2 ? (int)k - 2 : -1;
+    }
+    b->two_slabs = two_slabs;
   }
   auto class_bounds = [&](int c0, int c1, int *out) {
     // chunks [c0, c1) are sorted by falling length, so kernel classes fall too:
@@ -408,7 +417,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       return fail(PSA_ERR_HIP);
     }
     // slabs of the context: grown when this batch needs more, two once a batch needs two passes
-    const int want = b->passes.size() > 1 ? 2 : 1;
+    const int want = b->two_slabs ? 2 : 1;
     if (cap_units > c->slab_units || want > c->slab_count) {
       const size_t units = std::max(cap_units, c->slab_units);
       const int count = std::max(want, c->slab_count);
@@ -503,8 +512,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     if (piped) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
     for (size_t k = 0; k < b->passes.size(); ++k) {
       psa_batch::SlabPass &sp = b->passes[k];
-      const int buf = piped ? (int)(k & 1) : 0;
-      if (piped && k >= 2) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->passes[k - 2].ev_e, 0));
+      const int buf = sp.buf;
+      if (piped && sp.reuse_of >= 0) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->passes[(size_t)sp.reuse_of].ev_e, 0));
       for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
         const int c0 = sp.cls_c0[cls + 1], c1 = sp.cls_c0[cls];
         if (c1 <= c0) continue;
@@ -515,8 +524,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
         PSA_HIP(psa::launch_enum_prep(cls, P, sp_stream));
       }
       if (piped) {
-        PSA_HIP(hipEventRecord(c->ev_prep[buf], c->st_pre));
-        PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[buf], 0));
+        PSA_HIP(hipEventRecord(c->ev_prep[k & 1], c->st_pre));
+        PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[k & 1], 0));
       }
       psa::WaveParams W = sp.wave;
       W.chunks = b->d_chunks + sp.c0;

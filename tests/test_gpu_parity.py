@@ -241,6 +241,37 @@ def test_config3_shape_small(psa, ctx, oracle):
     check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
 
 
+def test_slab_passes(psa, oracle, monkeypatch):
+    """Enumeration in many slab passes (5 MB slabs, the smallest allowed; unit sub-runs of 1, 3 and 64
+    offsets): pass boundaries inside a Seq2 and between kernel variants, pre-pass and candidate
+    loop alternating over the two slabs."""
+    lens = [40, 300, 511, 512, 700, 1100, 2047, 2048, 2100, 4100]
+    seq1, seq2s = synth_problem(91, 4500, lens)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    monkeypatch.setenv("PSA_SLAB_MB", "5")
+    want = None
+    for ns in ("1", "3", "64", None):
+        if ns is None:
+            monkeypatch.delenv("PSA_ENUM_NS")
+        else:
+            monkeypatch.setenv("PSA_ENUM_NS", ns)
+        c = psa.Context(0)
+        c.set_seq1(seq1)
+        c.set_weights(w)
+        res = c.score_batch(seq2s)
+        if want is None:
+            check_against_oracle(oracle, seq1, seq2s, table, res)
+            want = [r.key() + r.enum_key() + tuple(r.enum_counts) for r in res]
+        else:
+            assert [r.key() + r.enum_key() + tuple(r.enum_counts) for r in res] == want
+        part = c.score_range(seq2s[-1], 100, 333)
+        e = oracle.enum_best(seq1, seq2s[-1], oracle.fixed_table(table, lens[-1])[1], 100, 333)
+        assert part.enum_key() == (e.n, e.k, e.offset, e.score)
+        assert part.key() == oracle.fast(seq1, seq2s[-1], table, 100, 333).as_tuple()
+        c.close()
+
+
 def test_long_seq2(psa, ctx, oracle):
     """Seq2 of 4095/4096/8000/8191 characters: the two largest kernel variants."""
     seq1, seq2s = synth_problem(77, 9000, [4095, 4096, 8000, 8191])

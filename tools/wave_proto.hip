@@ -116,6 +116,33 @@ __device__ __forceinline__ void full(const int *__restrict__ G, int qa, int qb, 
     };
     A(0); A(1); M(0); A(2); M(1); A(3); M(2); M(3);
   }
+#elif FULLV == 6
+  // as 5, 32 g values per step (two scalar loads in flight)
+  for (int q = qa; q < qb; q += 32) {
+    int g[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g[i] = G[q + i];
+    int t[8][K][4];
+    auto A = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][0] = vadd(g[4 * b], f[r]);
+        t[b][r][1] = vadd(g[4 * b + 1], f[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][2] = vadd(g[4 * b + 2], f[r]);
+        t[b][r][3] = vadd(g[4 * b + 3], f[r]);
+      }
+    };
+    auto M = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) vmax3(acc[r][0], t[b][r][0], t[b][r][1]);
+#pragma unroll
+      for (int r = 0; r < K; ++r) vmax3(acc[r][1], t[b][r][2], t[b][r][3]);
+    };
+    A(0); A(1); M(0); A(2); M(1); A(3); M(2); A(4); M(3); A(5); M(4); A(6); M(5); A(7); M(6); M(7);
+  }
 #elif FULLV == 4
   // add, add, max3 interleaved; a max3 consumes the sums of the previous pair of g values
   for (int q = qa; q < qb; q += 16) {
