@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--nseq2", type=int, default=256, help="Seq2 per GPU for --config c3")
     ap.add_argument("--stages", default="both", choices=["both", "enumerate", "resolve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="wait for every step before launching the next")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -180,11 +181,20 @@ def main():
     barrier()
     t0 = time.perf_counter()
     enum_ms = gpu_ms = 0.0
-    for _ in range(args.steps):
-        batch.launch(stages)  # returns when the step's kernels and the record copy have finished
-        em, tm = batch.timing()
-        enum_ms += em
-        gpu_ms += tm
+    if args.sync_steps:
+        for _ in range(args.steps):
+            batch.launch(stages)  # returns when the step's kernels and the record copy have finished
+            em, tm = batch.timing()
+            enum_ms += em
+            gpu_ms += tm
+    else:
+        # the K steps are enqueued back to back (they execute in order on the context's streams) and
+        # awaited once: the host's launch latency overlaps the previous step instead of idling the GPU
+        for _ in range(args.steps):
+            batch.enqueue(stages)
+        batch.wait()
+        em, tm = batch.timing()  # HIP events of the last step
+        enum_ms, gpu_ms = em * args.steps, tm * args.steps
     barrier()
     elapsed = time.perf_counter() - t0
 

@@ -93,6 +93,14 @@ int psa_batch_create_range(psa_ctx *ctx, const char *seq2, int32_t len2, int64_t
                            psa_batch **out);
 /* launches the kernels on data already resident in HBM and waits for them */
 int psa_batch_run(psa_batch *b, uint32_t stages);
+/* the two halves of psa_batch_run: enqueue puts one run on the context's streams and returns
+ * at once; wait blocks until the records of the most recently enqueued run are in host memory.
+ * Runs enqueued back to back (on this batch or on other batches of the context) execute in
+ * order, so a caller that streams many batches keeps the GPU busy while it prepares the next
+ * one -- the per-Seq2 blocking call of the reference (P/main.c:81, :130) has no such overlap.
+ * A batch holds one set of records: enqueueing it again before wait overwrites them. */
+int psa_batch_enqueue(psa_batch *b, uint32_t stages);
+int psa_batch_wait(psa_batch *b);
 /* copies the n records of the last run */
 int psa_batch_results(const psa_batch *b, psa_result *out);
 /* device time of the last run in milliseconds, from HIP events on the launch streams:

@@ -89,15 +89,13 @@ struct psa_batch {
   int nfwd = 0;
   float *d_fs = nullptr;
   psa::ActiveOffset *d_active = nullptr;
-  psa_result *d_out = nullptr;
-  psa_result *h_out = nullptr;  // pinned
+  psa_result *h_out = nullptr;  // pinned and mapped: psa_finalize writes the records straight into it
+  psa_result *d_out = nullptr;  // the device's address of h_out
   hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_init = nullptr, ev_res = nullptr;
-  uint32_t last_stages = 0xffffffffu;  // stages of the previous run
-  hipGraphExec_t graph_exec = nullptr;  // replayable capture of one run
-  uint32_t graph_stages = 0;
-  bool graph_failed = false;
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
+  bool pending = false, pending_timed = false;  // a run is enqueued, not yet waited for
+  bool acc_ready = false;  // the accumulators were reset after the previous run
 };
 
 extern "C" {
@@ -204,7 +202,10 @@ int psa_set_weights(psa_ctx *c, const float weights[4]) {
 
 void psa_batch_destroy(psa_batch *b) {
   if (!b) return;
-  if (b->ctx) (void)hipSetDevice(b->ctx->device);
+  if (b->ctx) {
+    (void)hipSetDevice(b->ctx->device);
+    if (b->ctx->st_enum) (void)hipStreamSynchronize(b->ctx->st_enum);  // the trailing reset may still run
+  }
   if (b->d_pool) (void)hipFree(b->d_pool);
   if (b->d_desc) (void)hipFree(b->d_desc);
   if (b->d_acc) (void)hipFree(b->d_acc);
@@ -218,9 +219,7 @@ void psa_batch_destroy(psa_batch *b) {
   if (b->d_fwd) (void)hipFree(b->d_fwd);
   if (b->d_fs) (void)hipFree(b->d_fs);
   if (b->d_active) (void)hipFree(b->d_active);
-  if (b->d_out) (void)hipFree(b->d_out);
   if (b->h_out) (void)hipHostFree(b->h_out);
-  if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   for (hipEvent_t e : {b->ev_first, b->ev_last, b->ev_init, b->ev_res})
     if (e) (void)hipEventDestroy(e);
   delete b;
@@ -452,9 +451,8 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   } while (0)
   if (n > 0) {
     PSA_HIP_B(hipMalloc((void **)&b->d_acc, (size_t)n * sizeof(psa::SeqAcc)));
-    PSA_HIP_B(hipMalloc((void **)&b->d_out, (size_t)n * sizeof(psa_result)));
-    PSA_HIP_B(hipHostMalloc((void **)&b->h_out, (size_t)n * sizeof(psa_result), hipHostMallocDefault));
-    PSA_HIP_B(hipMemcpy(b->d_out, b->tmpl.data(), (size_t)n * sizeof(psa_result), hipMemcpyHostToDevice));
+    PSA_HIP_B(hipHostMalloc((void **)&b->h_out, (size_t)n * sizeof(psa_result), hipHostMallocMapped));
+    PSA_HIP_B(hipHostGetDevicePointer((void **)&b->d_out, b->h_out, 0));
     std::memcpy(b->h_out, b->tmpl.data(), (size_t)n * sizeof(psa_result));
   }
   PSA_HIP_B(hipMalloc((void **)&b->d_counters, sizeof(unsigned)));
@@ -492,9 +490,16 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   psa_ctx *c = b->ctx;
   const bool resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
   PSA_HIP(hipEventRecord(b->ev_first, c->st_enum));
-  PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, 1, c->st_enum));
-  PSA_HIP(hipEventRecord(b->ev_init, c->st_enum));
-  PSA_HIP(psa::debug_sync("psa_init_acc"));
+  // psa_finalize resets the accumulators it has read, so only a batch's first run, or one after
+  // a failed run, needs the set-up kernel.
+  hipEvent_t ev_begin = b->ev_first;  // what the other streams wait for before they start
+  if (!b->acc_ready) {
+    PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, 1, c->st_enum));
+    PSA_HIP(psa::debug_sync("psa_init_acc"));
+    PSA_HIP(hipEventRecord(b->ev_init, c->st_enum));
+    ev_begin = b->ev_init;
+  }
+  b->acc_ready = false;
   *timed = false;
   if ((stages & PSA_STAGE_ENUMERATE) && b->nchunks > 0) {
     psa::EnumParams P{};
@@ -509,7 +514,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     // k - 1 reads the other slab; it waits for the candidate loop of pass k - 2 to let go.
     const bool piped = b->passes.size() > 1;
     hipStream_t sp_stream = piped ? c->st_pre : c->st_enum;
-    if (piped) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
+    if (piped) PSA_HIP(hipStreamWaitEvent(c->st_pre, ev_begin, 0));
     for (size_t k = 0; k < b->passes.size(); ++k) {
       psa_batch::SlabPass &sp = b->passes[k];
       const int buf = sp.buf;
@@ -556,12 +561,13 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   F.seq2_pool = b->d_pool;
   F.desc = b->d_desc;
   F.acc = b->d_acc;
+  F.nactive = b->d_counters;
   F.class_t = c->d_class_t;
   F.out = b->d_out;
   F.stages = stages;
   F.which = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   if (resolve) {
-    PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
+    PSA_HIP(hipStreamWaitEvent(c->st_res, ev_begin, 0));
     psa::ResolveParams P{};
     P.seq1 = c->d_seq1;
     P.len1 = c->len1;
@@ -585,65 +591,49 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   PSA_HIP(psa::launch_finalize(F, b->n, c->st_enum));
   PSA_HIP(psa::debug_sync("psa_finalize"));
   if (resolve) PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_res, 0));
-  PSA_HIP(hipMemcpyAsync(b->h_out, b->d_out, (size_t)b->n * sizeof(psa_result), hipMemcpyDeviceToHost, c->st_enum));
   PSA_HIP(hipEventRecord(b->ev_last, c->st_enum));
+  b->acc_ready = true;  // psa_finalize left the accumulators reset
   return PSA_OK;
 }
 
-int psa_batch_run(psa_batch *b, uint32_t stages) {
+int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
   if (!b) return PSA_ERR_ARG;
   if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   psa_ctx *c = b->ctx;
   b->ran = false;
+  b->pending = false;
+  if (b->n == 0) {
+    b->pending = true;
+    return PSA_OK;
+  }
+  PSA_HIP(hipSetDevice(c->device));
+  // (Capturing a run into a HIP graph and replaying it was measured: 0.460 against 0.463 ms per
+  // run of 4 x Seq2 = 2000, and events inside a graph do not time its kernels -- not used.)
+  bool timed = false;
+  {
+    int st = enqueue_run(b, stages, &timed);
+    if (st != PSA_OK) return st;
+  }
+  b->pending = true;
+  b->pending_timed = timed;
+  return PSA_OK;
+}
+
+int psa_batch_wait(psa_batch *b) {
+  if (!b) return PSA_ERR_ARG;
+  if (!b->pending) return PSA_ERR_STATE;
+  b->pending = false;
   if (b->n == 0) {
     b->ran = true;
     return PSA_OK;
   }
+  psa_ctx *c = b->ctx;
   PSA_HIP(hipSetDevice(c->device));
-  // The first run with a given set of stages launches kernel by kernel (it also sets
-  // the kernels' LDS attributes); the second captures the same sequence into a HIP
-  // graph, and later runs replay it: one launch per run instead of a dozen.
-  // Measured on MI355X the replay is no faster than the direct launches (0.460 vs 0.463 ms per
-  // run of 4 x Seq2 = 2000) and events recorded inside a graph do not time its kernels, so the
-  // graph path is opt-in: PSA_GRAPH=1.
-  static const bool graphs_off = std::getenv("PSA_GRAPH") == nullptr || std::getenv("PSA_DEBUG_SYNC") != nullptr;
-  bool launched = false;
-  if (!graphs_off && !b->graph_failed && b->last_stages == stages) {
-    if (!(b->graph_exec && b->graph_stages == stages)) {
-      if (b->graph_exec) {
-        (void)hipGraphExecDestroy(b->graph_exec);
-        b->graph_exec = nullptr;
-      }
-      hipGraph_t graph = nullptr;
-      bool timed_dummy = false;
-      hipError_t e = hipStreamBeginCapture(c->st_enum, hipStreamCaptureModeRelaxed);
-      int st = e == hipSuccess ? enqueue_run(b, stages, &timed_dummy) : PSA_ERR_HIP;
-      hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(c->st_enum, &graph) : e;
-      if (st == PSA_OK && e2 == hipSuccess && graph &&
-          hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-        b->graph_stages = stages;
-      } else {
-        b->graph_failed = true;  // fall back to kernel-by-kernel launches for this batch
-        b->graph_exec = nullptr;
-        (void)hipGetLastError();
-      }
-      if (graph) (void)hipGraphDestroy(graph);
-    }
-    if (b->graph_exec) {
-      PSA_HIP(hipGraphLaunch(b->graph_exec, c->st_enum));
-      launched = true;
-    }
-  }
-  bool timed = false;  // events recorded inside a replayed graph carry no times
-  if (!launched) {
-    int st = enqueue_run(b, stages, &timed);
-    if (st != PSA_OK) return st;
-  }
-  b->last_stages = stages;
-  PSA_HIP(hipStreamSynchronize(c->st_enum));
-  PSA_HIP(hipStreamSynchronize(c->st_res));
+  // ev_last is recorded on st_enum after it has waited for the other streams
+  PSA_HIP(hipEventSynchronize(b->ev_last));
   b->enum_ms = 0.f;
-  if (timed) {
+  b->total_ms = 0.f;
+  if (b->pending_timed) {
     for (psa_batch::SlabPass &sp : b->passes) {
       float ms = 0.f;
       PSA_HIP(hipEventElapsedTime(&ms, sp.ev_b, sp.ev_e));
@@ -653,6 +643,11 @@ int psa_batch_run(psa_batch *b, uint32_t stages) {
   PSA_HIP(hipEventElapsedTime(&b->total_ms, b->ev_first, b->ev_last));
   b->ran = true;
   return PSA_OK;
+}
+
+int psa_batch_run(psa_batch *b, uint32_t stages) {
+  int st = psa_batch_enqueue(b, stages);
+  return st == PSA_OK ? psa_batch_wait(b) : st;
 }
 
 int psa_batch_results(const psa_batch *b, psa_result *out) {

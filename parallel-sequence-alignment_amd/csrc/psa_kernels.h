@@ -59,9 +59,10 @@ struct FinalParams {
   const unsigned char *seq1;
   const unsigned char *seq2_pool;
   const SeqDesc *desc;
-  const SeqAcc *acc;
+  SeqAcc *acc;                   // read, then reset for the next run
+  unsigned *nactive;             // reset with the resolve half
   const unsigned char *class_t;  // residue class [seq2 code][seq1 code], stride 32
-  psa_result *out;
+  psa_result *out;               // pinned host memory, written directly
   uint32_t stages;  // stages of the run
   uint32_t which;   // PSA_STAGE_* bits: the halves of the records this launch fills
 };

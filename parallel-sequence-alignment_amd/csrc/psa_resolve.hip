@@ -391,6 +391,22 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   const SeqAcc a = P.acc[i];
   psa_result *r = P.out + i;
   const int tid = threadIdx.x;
+  // Each half is the last reader of its accumulators in a run and leaves them reset for the
+  // next one (what psa_init_acc writes), so a resident batch needs no set-up kernel per run.
+  __syncthreads();
+  if (tid == 0) {
+    SeqAcc *w = P.acc + i;
+    if (P.which & PSA_STAGE_RESOLVE) {
+      w->res_loc = ~0ull;
+      w->res_key = 0u;
+      w->res_p = INT_MAX;
+      if (i == 0) *P.nactive = 0u;
+    }
+    if (P.which & PSA_STAGE_ENUMERATE) {
+      w->enum_key = 0ull;
+      w->enum_loc = ~0ull;
+    }
+  }
   if (uni((int)(P.which & PSA_STAGE_RESOLVE))) {
     const bool res_ok = uni((P.stages & PSA_STAGE_RESOLVE) && a.res_loc != ~0ull && a.res_p != INT_MAX);
     if (res_ok) {

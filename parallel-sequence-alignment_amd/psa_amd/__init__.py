@@ -75,6 +75,8 @@ def lib():
     L.psa_batch_create.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.POINTER(vp)]
     L.psa_batch_create_range.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp)]
     L.psa_batch_run.argtypes = [vp, C.c_uint32]
+    L.psa_batch_enqueue.argtypes = [vp, C.c_uint32]
+    L.psa_batch_wait.argtypes = [vp]
     L.psa_batch_results.argtypes = [vp, C.POINTER(Result)]
     L.psa_batch_timing.argtypes = [vp, f32p, f32p]
     L.psa_batch_size.argtypes = [vp]
@@ -283,6 +285,13 @@ class Batch:
     def launch(self, stages=STAGE_BOTH):
         """Runs the kernels on the resident data and waits; no host copies of inputs."""
         _check(lib().psa_batch_run(self._h, stages), "psa_batch_run")
+
+    def enqueue(self, stages=STAGE_BOTH):
+        """Puts one run on the context's streams and returns at once; wait() completes it."""
+        _check(lib().psa_batch_enqueue(self._h, stages), "psa_batch_enqueue")
+
+    def wait(self):
+        _check(lib().psa_batch_wait(self._h), "psa_batch_wait")
 
     def results(self):
         out = (Result * max(self.n, 1))()

@@ -111,6 +111,17 @@ def test_config2_shape(psa, ctx, oracle):
     assert [r.key() + r.enum_key() for r in again] == [r.key() + r.enum_key() for r in res]
     em, tm = b.timing()
     assert em > 0 and tm >= em
+    # three runs enqueued back to back, one wait: the records of the last one
+    with pytest.raises(psa.PsaError):
+        b.wait()  # nothing enqueued
+    for _ in range(3):
+        b.enqueue()
+    b.wait()
+    assert [r.key() + r.enum_key() for r in b.results()] == [r.key() + r.enum_key() for r in res]
+    b.enqueue(psa.STAGE_RESOLVE)
+    b.wait()
+    assert [r.key() for r in b.results()] == [r.key() for r in res]
+    assert all(r.enum_n == 0 for r in b.results())
     b.close()
 
 
