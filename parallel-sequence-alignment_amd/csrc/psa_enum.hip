@@ -281,7 +281,8 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
   const int r1 = min(r0 + d.enum_ns, ch.ns);
   const int L2 = d.len2;
   const int nruns = (L2 + 63) >> 6;
-  const int qend = 64 * nruns;
+  const int qend = 64 * nruns;           // row length
+  const int qlast = (L2 + 15) & ~15;     // the candidate loop stops at the 16-value step that holds q = L2 - 1
   const int pc0 = w * R;
   const int *__restrict__ F = fg + ((size_t)ch.fg_row + (size_t)r0 * (2 * nruns + 1)) * 64;
   int fn[R], acc[R][2];
@@ -300,7 +301,7 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
       for (int r = 0; r < R; ++r) fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
     }
-    WavePhases<R, R>::run(G, pc0, qend, f, acc);
+    WavePhases<R, R>::run(G, pc0, qlast, f, acc);
     wave_diag<R>(G, pc0, nruns, lane, f, acc);
   }
   // best fixed-point score of this unit and the smallest p attaining it
