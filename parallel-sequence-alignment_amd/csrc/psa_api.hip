@@ -49,6 +49,8 @@ struct psa_ctx {
   size_t slab_units = 0;  // capacity of each slab in runs of 64 int32
   int slab_count = 0;
   hipEvent_t ev_prep[2] = {nullptr, nullptr};
+  hipEvent_t slab_reader[2] = {nullptr, nullptr};  // end of the last candidate loop that read slab i (a batch's event)
+  psa_batch *slab_reader_batch[2] = {nullptr, nullptr};
   unsigned char *d_seq1 = nullptr;
   int64_t len1 = 0;
   float table[PSA_TABLE_SIZE];
@@ -73,8 +75,7 @@ struct psa_batch {
   // [c0, c1), whose rows fit one slab
   struct SlabPass {
     int c0 = 0, c1 = 0;
-    int buf = 0;        // slab of the context this pass uses
-    int reuse_of = -1;  // earlier pass whose rows it overwrites (its candidate loop must be done), -1 = none
+    int buf = 0;  // slab of the context this pass uses
     int cls_c0[psa::kEnumClasses + 1] = {};  // chunks of kernel class k: [cls_c0[k + 1], cls_c0[k]) (classes fall)
     psa::WaveParams wave{};
     hipEvent_t ev_b = nullptr, ev_e = nullptr;
@@ -91,10 +92,11 @@ struct psa_batch {
   psa::ActiveOffset *d_active = nullptr;
   psa_result *h_out = nullptr;  // pinned and mapped: psa_finalize writes the records straight into it
   psa_result *d_out = nullptr;  // the device's address of h_out
-  hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_init = nullptr, ev_res = nullptr;
+  // start of the first / end of the last kernel on the enumeration side and on the resolve side
+  hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_res_first = nullptr, ev_res = nullptr, ev_init = nullptr;
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
-  bool pending = false, pending_timed = false;  // a run is enqueued, not yet waited for
+  bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
   bool acc_ready = false;  // the accumulators were reset after the previous run
 };
 
@@ -204,7 +206,13 @@ void psa_batch_destroy(psa_batch *b) {
   if (!b) return;
   if (b->ctx) {
     (void)hipSetDevice(b->ctx->device);
-    if (b->ctx->st_enum) (void)hipStreamSynchronize(b->ctx->st_enum);  // the trailing reset may still run
+    if (b->pending) (void)hipDeviceSynchronize();  // a run nobody waited for
+    for (int i = 0; i < 2; ++i)
+      if (b->ctx->slab_reader_batch[i] == b) {
+        (void)hipEventSynchronize(b->ctx->slab_reader[i]);
+        b->ctx->slab_reader[i] = nullptr;
+        b->ctx->slab_reader_batch[i] = nullptr;
+      }
   }
   if (b->d_pool) (void)hipFree(b->d_pool);
   if (b->d_desc) (void)hipFree(b->d_desc);
@@ -220,7 +228,7 @@ void psa_batch_destroy(psa_batch *b) {
   if (b->d_fs) (void)hipFree(b->d_fs);
   if (b->d_active) (void)hipFree(b->d_active);
   if (b->h_out) (void)hipHostFree(b->h_out);
-  for (hipEvent_t e : {b->ev_first, b->ev_last, b->ev_init, b->ev_res})
+  for (hipEvent_t e : {b->ev_first, b->ev_last, b->ev_init, b->ev_res, b->ev_res_first})
     if (e) (void)hipEventDestroy(e);
   delete b;
 }
@@ -362,7 +370,6 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     bool two_slabs = b->passes.size() > 1;
     for (size_t k = 0; k < b->passes.size(); ++k) {
       b->passes[k].buf = (int)(k & 1);
-      b->passes[k].reuse_of = k >= 2 ? (int)k - 2 : -1;
     }
     b->two_slabs = two_slabs;
   }
@@ -420,6 +427,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     if (cap_units > c->slab_units || want > c->slab_count) {
       const size_t units = std::max(cap_units, c->slab_units);
       const int count = std::max(want, c->slab_count);
+      (void)hipDeviceSynchronize();  // runs enqueued on other batches may still use the old slabs
       for (int i = 0; i < 2; ++i) {
         if (c->d_slab[i]) (void)hipFree(c->d_slab[i]);
         c->d_slab[i] = nullptr;
@@ -460,7 +468,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     PSA_HIP_B(hipMalloc((void **)&b->d_fs, (size_t)fs_total * sizeof(float)));
     PSA_HIP_B(hipMalloc((void **)&b->d_active, (size_t)fs_total * sizeof(psa::ActiveOffset)));
   }
-  for (hipEvent_t *e : {&b->ev_first, &b->ev_last, &b->ev_init, &b->ev_res}) PSA_HIP_B(hipEventCreate(e));
+  for (hipEvent_t *e : {&b->ev_first, &b->ev_last, &b->ev_init, &b->ev_res, &b->ev_res_first}) PSA_HIP_B(hipEventCreate(e));
   for (psa_batch::SlabPass &sp : b->passes) {
     PSA_HIP_B(hipEventCreate(&sp.ev_b));
     PSA_HIP_B(hipEventCreate(&sp.ev_e));
@@ -483,25 +491,31 @@ int psa_batch_create_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s
 
 int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
 
-// Enqueues one run on the two streams of the context: accumulator set-up, then the
-// enumeration kernels on st_enum and the resolve kernels on st_res side by side, then
-// the result records and their copy to pinned host memory.  No host synchronisation.
+// Enqueues one run on the streams of the context: the enumeration (pre-pass on st_pre,
+// candidate loop, locate and the enumeration half of the records on st_enum) and the resolve
+// chain with its half of the records on st_res, side by side.  No host synchronisation, and in
+// the steady state no stream waits for another except the candidate loop for its pre-pass:
+// the events that time the run ride on kernel dispatches, the host waits for both record
+// kernels, and the accumulators are left reset by their last readers.
 static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   psa_ctx *c = b->ctx;
   const bool resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
-  PSA_HIP(hipEventRecord(b->ev_first, c->st_enum));
-  // psa_finalize resets the accumulators it has read, so only a batch's first run, or one after
-  // a failed run, needs the set-up kernel.
-  hipEvent_t ev_begin = b->ev_first;  // what the other streams wait for before they start
-  if (!b->acc_ready) {
+  const bool enumerate = (stages & PSA_STAGE_ENUMERATE) && b->nchunks > 0;
+  // only a batch's first run, or one after a failed run, needs the set-up kernel
+  const bool init = !b->acc_ready;
+  if (init) {
     PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, 1, c->st_enum));
     PSA_HIP(psa::debug_sync("psa_init_acc"));
+    if (b->nchunks > 0)
+      PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, (size_t)b->nchunks * sizeof(unsigned long long), c->st_enum));
     PSA_HIP(hipEventRecord(b->ev_init, c->st_enum));
-    ev_begin = b->ev_init;
+    PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
+    PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
   }
   b->acc_ready = false;
   *timed = false;
-  if ((stages & PSA_STAGE_ENUMERATE) && b->nchunks > 0) {
+  hipEvent_t ev_first = b->ev_first;  // start of the first kernel on the enumeration side
+  if (enumerate) {
     psa::EnumParams P{};
     P.seq1 = c->d_seq1;
     P.len1 = c->len1;
@@ -509,16 +523,20 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.desc = b->d_desc;
     P.acc = b->d_acc;
     P.table_t = c->d_table_t;
-    // One pass: pre-pass and candidate loop follow each other on st_enum.  Several: the
-    // pre-pass of pass k runs on st_pre into slab k % 2 while the candidate loop of pass
-    // k - 1 reads the other slab; it waits for the candidate loop of pass k - 2 to let go.
+    // A pre-pass may fill a slab as soon as the last candidate loop that read it has finished,
+    // so it runs beside the candidate loop of the pass before it (on the other slab) and, for
+    // runs enqueued back to back, beside the tail (locate, records) of the run before.
     const bool piped = b->passes.size() > 1;
-    hipStream_t sp_stream = piped ? c->st_pre : c->st_enum;
-    if (piped) PSA_HIP(hipStreamWaitEvent(c->st_pre, ev_begin, 0));
     for (size_t k = 0; k < b->passes.size(); ++k) {
       psa_batch::SlabPass &sp = b->passes[k];
       const int buf = sp.buf;
-      if (piped && sp.reuse_of >= 0) PSA_HIP(hipStreamWaitEvent(c->st_pre, b->passes[(size_t)sp.reuse_of].ev_e, 0));
+      if (c->slab_reader[buf]) PSA_HIP(hipStreamWaitEvent(c->st_pre, c->slab_reader[buf], 0));
+      int last_cls = -1;
+      for (int cls = 0; cls < psa::kEnumClasses; ++cls)
+        if (sp.cls_c0[cls] > sp.cls_c0[cls + 1]) {
+          last_cls = cls;
+          break;
+        }
       for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
         const int c0 = sp.cls_c0[cls + 1], c1 = sp.cls_c0[cls];
         if (c1 <= c0) continue;
@@ -526,12 +544,10 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
         P.chunk_best = b->d_chunk_best + c0;
         P.nchunks = c1 - c0;
         P.fg = c->d_slab[buf];
-        PSA_HIP(psa::launch_enum_prep(cls, P, sp_stream));
+        PSA_HIP(psa::launch_enum_prep(cls, P, c->st_pre, ev_first, cls == last_cls ? c->ev_prep[k & 1] : nullptr));
+        ev_first = nullptr;
       }
-      if (piped) {
-        PSA_HIP(hipEventRecord(c->ev_prep[k & 1], c->st_pre));
-        PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[k & 1], 0));
-      }
+      PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[k & 1], 0));
       psa::WaveParams W = sp.wave;
       W.chunks = b->d_chunks + sp.c0;
       W.chunk_best = b->d_chunk_best + sp.c0;
@@ -541,9 +557,9 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // to three workgroups of 8 waves per CU
       int lds = (resolve || piped) ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
-      PSA_HIP(hipEventRecord(sp.ev_b, c->st_enum));
-      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, lds, c->st_enum));
-      PSA_HIP(hipEventRecord(sp.ev_e, c->st_enum));
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, lds, c->st_enum, sp.ev_b, sp.ev_e));
+      c->slab_reader[buf] = sp.ev_e;
+      c->slab_reader_batch[buf] = b;
     }
     for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
       const int c0 = b->cls_c0[cls + 1], c1 = b->cls_c0[cls];
@@ -567,7 +583,6 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   F.stages = stages;
   F.which = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   if (resolve) {
-    PSA_HIP(hipStreamWaitEvent(c->st_res, ev_begin, 0));
     psa::ResolveParams P{};
     P.seq1 = c->d_seq1;
     P.len1 = c->len1;
@@ -581,18 +596,15 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.nactive = b->d_counters;
     P.pchunks = (b->max_len2 + 255) / 256;
     int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
-    PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res));
+    PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res, b->ev_res_first));
     // the float32 half of the records is filled on the resolve stream, beside the enumeration
     F.which = PSA_STAGE_RESOLVE;
-    PSA_HIP(psa::launch_finalize(F, b->n, c->st_res));
-    PSA_HIP(hipEventRecord(b->ev_res, c->st_res));
+    PSA_HIP(psa::launch_finalize(F, b->n, c->st_res, nullptr, b->ev_res));
     F.which = PSA_STAGE_ENUMERATE;
   }
-  PSA_HIP(psa::launch_finalize(F, b->n, c->st_enum));
+  PSA_HIP(psa::launch_finalize(F, b->n, c->st_enum, ev_first, b->ev_last));
   PSA_HIP(psa::debug_sync("psa_finalize"));
-  if (resolve) PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_res, 0));
-  PSA_HIP(hipEventRecord(b->ev_last, c->st_enum));
-  b->acc_ready = true;  // psa_finalize left the accumulators reset
+  b->acc_ready = true;  // psa_finalize leaves the accumulators reset
   return PSA_OK;
 }
 
@@ -616,6 +628,7 @@ int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
   }
   b->pending = true;
   b->pending_timed = timed;
+  b->pending_resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
   return PSA_OK;
 }
 
@@ -629,8 +642,9 @@ int psa_batch_wait(psa_batch *b) {
   }
   psa_ctx *c = b->ctx;
   PSA_HIP(hipSetDevice(c->device));
-  // ev_last is recorded on st_enum after it has waited for the other streams
+  // the two record kernels are the last of their streams
   PSA_HIP(hipEventSynchronize(b->ev_last));
+  if (b->pending_resolve) PSA_HIP(hipEventSynchronize(b->ev_res));
   b->enum_ms = 0.f;
   b->total_ms = 0.f;
   if (b->pending_timed) {
@@ -640,7 +654,13 @@ int psa_batch_wait(psa_batch *b) {
       b->enum_ms += ms;
     }
   }
-  PSA_HIP(hipEventElapsedTime(&b->total_ms, b->ev_first, b->ev_last));
+  // first kernel start to last kernel end over both sides
+  for (hipEvent_t first : {b->ev_first, b->pending_resolve ? b->ev_res_first : nullptr})
+    for (hipEvent_t last : {b->ev_last, b->pending_resolve ? b->ev_res : nullptr}) {
+      float ms = 0.f;
+      if (first && last && hipEventElapsedTime(&ms, first, last) == hipSuccess) b->total_ms = std::max(b->total_ms, ms);
+    }
+  (void)hipGetLastError();
   b->ran = true;
   return PSA_OK;
 }

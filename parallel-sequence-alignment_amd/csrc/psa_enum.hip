@@ -26,6 +26,8 @@
 // Instruction mix (measured on MI355X): v_add_u32 issues at full rate, every integer
 // or float min/max at half rate, so two candidates are folded into one v_max3_i32:
 // 2 adds + 1 max3 per two candidates.
+#include <hip/hip_ext.h>
+
 #include "psa_device.h"
 
 namespace psa {
@@ -125,7 +127,6 @@ __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
   const SeqDesc d = load_desc(P.desc + ch.seq);
   const int L2 = d.len2;
   const int npos = 64 * ((L2 + 63) >> 6);
-  if (tid == 0) P.chunk_best[c] = 0ull;
   int bro[R];
   int win0;
   enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
@@ -358,12 +359,18 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
     const Chunk ch = load_chunk(P.chunks + c);
     const unsigned long long ek = P.acc[ch.seq].enum_key;
     const unsigned long long ck = P.chunk_best[c];
-    if (uni((int)(ek != ck))) continue;
+    // This kernel is the last reader of chunk_best in a run and leaves it zeroed for the next.
+    // A wave that reads the zero instead of ck takes the same branch: ek is never 0.
+    if (uni((int)(ek != ck))) {
+      if (tid == 0) P.chunk_best[c] = 0ull;
+      continue;
+    }
     const SeqDesc d = load_desc(P.desc + ch.seq);
     const int L2 = d.len2;
     int bro[R];
     int win0;
     __syncthreads();
+    if (tid == 0) P.chunk_best[c] = 0ull;
     enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
     const int G = uni((int)((uint32_t)(ek >> 32) ^ 0x80000000u));
     const int pstar = uni((int)(0xffffffffu - (uint32_t)ek));
@@ -412,10 +419,11 @@ static hipError_t set_lds_attr() {
 }
 
 template <int NT, int R>
-static hipError_t launch_prep_t(const EnumParams &P, hipStream_t st) {
+static hipError_t launch_prep_t(const EnumParams &P, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   hipError_t e = set_lds_attr<NT, R>();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((psa_enum_prep<NT, R>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st, P);
+  hipExtLaunchKernelGGL((psa_enum_prep<NT, R>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st, ev_start,
+                        ev_stop, 0, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_enum_prep");
 }
@@ -429,9 +437,11 @@ static hipError_t launch_locate_t(const EnumParams &P, int grid, hipStream_t st)
   return debug_sync("psa_enum_locate");
 }
 
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, int lds_bytes, hipStream_t st) {
-  if (P.nunits <= 0) return hipSuccess;
-  hipLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st, fg, P);
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, int lds_bytes, hipStream_t st, hipEvent_t ev_start,
+                            hipEvent_t ev_stop) {
+  // the events ride on the kernel's own dispatch packet: no marker packets before or after it
+  hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st, ev_start,
+                        ev_stop, 0, fg, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return debug_sync("psa_enum_wave");
@@ -461,15 +471,15 @@ int enum_class_lds_bytes(int c) {
 
 int enum_class_threads(int c) { return c < 2 ? 256 : (c < 4 ? 512 : 1024); }
 
-hipError_t launch_enum_prep(int cls, const EnumParams &P, hipStream_t st) {
+hipError_t launch_enum_prep(int cls, const EnumParams &P, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (P.nchunks <= 0) return hipSuccess;
   switch (cls) {
-    case 0: return launch_prep_t<256, 1>(P, st);
-    case 1: return launch_prep_t<256, 2>(P, st);
-    case 2: return launch_prep_t<512, 2>(P, st);
-    case 3: return launch_prep_t<512, 4>(P, st);
-    case 4: return launch_prep_t<1024, 4>(P, st);
-    case 5: return launch_prep_t<1024, 8>(P, st);
+    case 0: return launch_prep_t<256, 1>(P, st, ev_start, ev_stop);
+    case 1: return launch_prep_t<256, 2>(P, st, ev_start, ev_stop);
+    case 2: return launch_prep_t<512, 2>(P, st, ev_start, ev_stop);
+    case 3: return launch_prep_t<512, 4>(P, st, ev_start, ev_stop);
+    case 4: return launch_prep_t<1024, 4>(P, st, ev_start, ev_stop);
+    case 5: return launch_prep_t<1024, 8>(P, st, ev_start, ev_stop);
     default: return hipErrorInvalidValue;
   }
 }

@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "psa_device.h"
 
 namespace psa {
@@ -475,7 +477,8 @@ static size_t tie_lds(int max_len2) {
   return (size_t)kDevTable * 4 + 4 * (size_t)tie_d0_len(max_len2) + 8 * (size_t)tie_d12_len(max_len2);
 }
 
-hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st) {
+hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,
+                          hipEvent_t ev_start) {
   static size_t attr_bytes = 0;
   hipError_t e;
   const size_t tb = tie_lds(max_len2);
@@ -489,7 +492,7 @@ hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2,
     if (e != hipSuccess) return e;
     attr_bytes = tb;
   }
-  hipLaunchKernelGGL(psa_fwd, dim3(nfwd_blocks), dim3(256), fwd_lds(max_len2), st, P);
+  hipExtLaunchKernelGGL(psa_fwd, dim3(nfwd_blocks), dim3(256), fwd_lds(max_len2), st, ev_start, nullptr, 0, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = debug_sync("psa_fwd")) != hipSuccess) return e;
   hipLaunchKernelGGL(psa_collect, dim3(nfwd_blocks), dim3(256), 0, st, P);
@@ -503,8 +506,8 @@ hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2,
   return debug_sync("psa_first_q");
 }
 
-hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st) {
-  hipLaunchKernelGGL(psa_finalize, dim3(n), dim3(256), 0, st, P);
+hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  hipExtLaunchKernelGGL(psa_finalize, dim3(n), dim3(256), 0, st, ev_start, ev_stop, 0, P);
   return hipGetLastError();
 }
 
