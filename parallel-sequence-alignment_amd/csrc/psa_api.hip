@@ -51,6 +51,7 @@ struct psa_ctx {
   hipEvent_t ev_prep[2] = {nullptr, nullptr};
   hipEvent_t slab_reader[2] = {nullptr, nullptr};  // end of the last candidate loop that read slab i (a batch's event)
   psa_batch *slab_reader_batch[2] = {nullptr, nullptr};
+  int slab_flip = 0;
   unsigned char *d_seq1 = nullptr;
   int64_t len1 = 0;
   float table[PSA_TABLE_SIZE];
@@ -78,7 +79,9 @@ struct psa_batch {
     int buf = 0;  // slab of the context this pass uses
     int cls_c0[psa::kEnumClasses + 1] = {};  // chunks of kernel class k: [cls_c0[k + 1], cls_c0[k]) (classes fall)
     psa::WaveParams wave{};
-    hipEvent_t ev_b = nullptr, ev_e = nullptr;
+    // start and end of the candidate loop, one pair per slab (a one-pass batch alternates slabs)
+    hipEvent_t ev_b[2] = {nullptr, nullptr}, ev_e[2] = {nullptr, nullptr};
+    int last_buf = 0;
   };
   std::vector<SlabPass> passes;
   bool two_slabs = false;
@@ -221,8 +224,10 @@ void psa_batch_destroy(psa_batch *b) {
   if (b->d_chunks) (void)hipFree(b->d_chunks);
   if (b->d_chunk_best) (void)hipFree(b->d_chunk_best);
   for (psa_batch::SlabPass &sp : b->passes) {
-    if (sp.ev_b) (void)hipEventDestroy(sp.ev_b);
-    if (sp.ev_e) (void)hipEventDestroy(sp.ev_e);
+    for (int i = 0; i < 2; ++i) {
+      if (sp.ev_b[i]) (void)hipEventDestroy(sp.ev_b[i]);
+      if (sp.ev_e[i]) (void)hipEventDestroy(sp.ev_e[i]);
+    }
   }
   if (b->d_fwd) (void)hipFree(b->d_fwd);
   if (b->d_fs) (void)hipFree(b->d_fs);
@@ -423,7 +428,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       return fail(PSA_ERR_HIP);
     }
     // slabs of the context: grown when this batch needs more, two once a batch needs two passes
-    const int want = b->two_slabs ? 2 : 1;
+    const int want = 2;
     if (cap_units > c->slab_units || want > c->slab_count) {
       const size_t units = std::max(cap_units, c->slab_units);
       const int count = std::max(want, c->slab_count);
@@ -470,8 +475,10 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   }
   for (hipEvent_t *e : {&b->ev_first, &b->ev_last, &b->ev_init, &b->ev_res, &b->ev_res_first}) PSA_HIP_B(hipEventCreate(e));
   for (psa_batch::SlabPass &sp : b->passes) {
-    PSA_HIP_B(hipEventCreate(&sp.ev_b));
-    PSA_HIP_B(hipEventCreate(&sp.ev_e));
+    for (int i = 0; i < 2; ++i) {
+      PSA_HIP_B(hipEventCreate(&sp.ev_b[i]));
+      PSA_HIP_B(hipEventCreate(&sp.ev_e[i]));
+    }
   }
 #undef PSA_HIP_B
   *out = b;
@@ -529,7 +536,9 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     const bool piped = b->passes.size() > 1;
     for (size_t k = 0; k < b->passes.size(); ++k) {
       psa_batch::SlabPass &sp = b->passes[k];
-      const int buf = sp.buf;
+      // a one-pass batch alternates between the slabs from run to run, so that the pre-pass of a
+      // run enqueued behind another runs beside that one's candidate loop
+      const int buf = piped ? sp.buf : (c->slab_flip ^= 1);
       if (c->slab_reader[buf]) PSA_HIP(hipStreamWaitEvent(c->st_pre, c->slab_reader[buf], 0));
       int last_cls = -1;
       for (int cls = 0; cls < psa::kEnumClasses; ++cls)
@@ -557,8 +566,9 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // to three workgroups of 8 waves per CU
       int lds = (resolve || piped) ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
-      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, lds, c->st_enum, sp.ev_b, sp.ev_e));
-      c->slab_reader[buf] = sp.ev_e;
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, lds, c->st_enum, sp.ev_b[buf], sp.ev_e[buf]));
+      sp.last_buf = buf;
+      c->slab_reader[buf] = sp.ev_e[buf];
       c->slab_reader_batch[buf] = b;
     }
     for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
@@ -650,7 +660,7 @@ int psa_batch_wait(psa_batch *b) {
   if (b->pending_timed) {
     for (psa_batch::SlabPass &sp : b->passes) {
       float ms = 0.f;
-      PSA_HIP(hipEventElapsedTime(&ms, sp.ev_b, sp.ev_e));
+      PSA_HIP(hipEventElapsedTime(&ms, sp.ev_b[sp.last_buf], sp.ev_e[sp.last_buf]));
       b->enum_ms += ms;
     }
   }
