@@ -111,17 +111,19 @@ def cpu_baseline(seq1, seq2, budget_s=12.0):
                       % (S, n1, t1, nm, cores, tm, L2, L1)}
 
 
-def measured_traffic(cfg):
-    """HBM bytes per launch of the enumeration kernel as the TCC counters saw them in the committed
-    rocprofv3 run of this workload (profiles/r01_c2_pmc.json); None for workloads not profiled."""
+def measured_traffic(cfg, f_bytes):
+    """Memory-side bytes per launch of the candidate-loop kernel as the TCC counters saw them in the
+    committed rocprofv3 run of this workload (profiles/r01_c2_pmc.json); None for workloads not
+    profiled.  Calibration (profiles/r01_fetch_size_calibration.txt): the kernel's scalar reads are
+    counted in full, its dword-per-lane reads of the f rows (f_bytes) at half."""
     path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
     if cfg != "c2" or not os.path.exists(path):
         return None
     with open(path) as f:
         kernels = json.load(f)["kernels"]
     for name, c in kernels.items():
-        if "psa_enum_main" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        if "psa_enum_wave" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 + 0.5 * f_bytes
     return None
 
 
@@ -239,15 +241,24 @@ def main():
         if stages & psa_amd.STAGE_ENUMERATE and enum_ms > 0:
             kern_s = enum_ms / 1e3 / args.steps  # this rank's average enumeration-kernel time per step
             achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
+            # slab rows the candidate loop reads: 4-byte f and g per (offset, position), once each
+            slab_bytes = sum(8.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
+                             for s2, r in zip(seq2s, res) if r.candidates > 0) if rng is None else \
+                8.0 * len(seq2s[0]) * (rng[1] - rng[0])
             out["roofline"] = {
-                "bound": "valu-int32", "kernel": "psa_enum_main",
+                "bound": "valu-int32", "kernel": "psa_enum_wave",
                 "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
-                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config),
-                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run)",
+                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config, slab_bytes / 2),
+                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs, plus the half of "
+                                "the f-row reads that FETCH_SIZE does not count; Infinity-Cache hits included)",
                 "kernel_ms": kern_s * 1e3,
-                "note": "2 int32 lane-ops (add + max) per candidate x candidates per launch / HIP-event time of "
-                        "the enumeration kernel on its own stream; the kernel reads Seq1 + Seq2 (a few KB) and "
-                        "writes one 8-byte key per chunk, so neither HBM nor MFMA bounds it",
+                "hbm_bytes_algorithmic": slab_bytes,
+                "hbm_frac": slab_bytes / kern_s / 8.0e12,
+                "note": "2 int32 lane-ops (add + max) per candidate x candidates per step / HIP-event time of "
+                        "the candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
+                        "their stream; the kernel reads 8 bytes of slab per (offset, position) against "
+                        "L2/2 candidates each (hbm_frac of the 8 TB/s peak), so INT32 VALU issue bounds it, "
+                        "not HBM or MFMA",
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(seq1, seq2s[0])
