@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the host-buffer entry points (upload + work lists + kernels + download per call) on the
-benchmark workload, for the PCIe-inclusive figure quoted in DESIGN.md."""
+benchmark workload: the PCIe-inclusive figure."""
 import os
 import sys
 import time
