@@ -310,7 +310,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     r.status = PSA_OK;
     b->max_len2 = std::max<int>(b->max_len2, (int)L2);
     b->nvalid++;
-    for (int64_t s0 = sb; s0 < se; s0 += 256) fwd.push_back(psa::FwdBlock{i, (int32_t)s0});
+    for (int64_t s0 = sb; s0 < se; s0 += psa::kFwdOffsets) fwd.push_back(psa::FwdBlock{i, (int32_t)s0});
   }
   b->total_offsets = fs_total;
 

@@ -45,7 +45,9 @@ struct Chunk {
   uint32_t fg_row;  // first row of the chunk in the slab, in units of 64 int32
 };
 
-// A block of up to 256 consecutive offsets of one Seq2 for the forward recurrence.
+// A block of up to kFwdOffsets consecutive offsets of one Seq2 for the forward recurrence
+// (4 waves x 62: two lanes of every wave only feed their neighbours).
+constexpr int kFwdOffsets = 248;
 struct FwdBlock {
   int32_t seq;
   int32_t s0;

@@ -37,18 +37,38 @@ __global__ void psa_init_acc(SeqAcc *acc, int n, unsigned *counters, int ncounte
 // ---------------------------------------------------------------------------------
 // float32 resolve, pass 1: per-offset maximum over all (n,k); lanes = offsets.
 // State before Seq2 position j: a (no deletion yet), b (one), c (two).
-//   a' = a + T[A[s+j]][B[j]]
-//   b' = max(a, b + T[A[s+j-1]][B[j]])      delete j, or keep it after one deletion
-//   c' = max(b, c + T[A[s+j-2]][B[j]])
-// Rounding is monotone, so taking the max before continuing the chain is exact.
+//   a' = a + x0,  b' = max(a, b + x1),  c' = max(b, c + x2),   x_d = T[A[s+j-d]][B[j]]
+// (delete j, or keep it after d deletions).  Rounding is monotone, so taking the max
+// before continuing the chain is exact.
 //
-// LDS: table | Seq2 codes packed 4 per word | Seq1 window as byte offsets (4 * code)
-// Steps run in groups of four.  The twelve table entries of group g+1 are fetched
-// while the chain of group g is computed; Seq1 offsets and the Seq2 word are
-// fetched two groups ahead, so no LDS latency sits on the dependent chain.
+// Consecutive lanes hold consecutive offsets, so x1 of lane l is x0 of lane l - 1 and x2
+// is x0 of lane l - 2 at the same step: one LDS table read per lane and step, the other
+// two entries arrive through wave-wide lane shifts (DPP wave_shr:1).  Lanes 0 and 1 of a
+// wave have no left neighbours; they run the two offsets below the wave's first and are
+// not used, so a wave yields 62 offsets and a block kFwdOffsets = 248.
+// The kernel runs one wave per SIMD and is bound by how fast that wave can issue, i.e.
+// by instructions per step: the Seq1 codes and the Seq2 row offsets of a group of four
+// steps are fetched two groups ahead, the table entries one group ahead, so no LDS
+// latency sits on the dependent chain.
+//
+// LDS: table | row byte offsets of Seq2 (128 * code per position) | Seq1 window as byte
+// offsets (4 * code)
 // ---------------------------------------------------------------------------------
-__host__ __device__ inline int fwd_bwords(int len2) { return (len2 + 3) / 4 + 4; }
-__host__ __device__ inline int fwd_window(int len2) { return 258 + len2 + 12; }
+__host__ __device__ inline int fwd_rows(int len2) { return ((len2 + 3) / 4) * 4 + 16; }
+__host__ __device__ inline int fwd_window(int len2) { return kFwdOffsets + 2 + len2 + 16; }
+
+__device__ __forceinline__ float lane_shr1(float v) {
+  // lane l receives lane l - 1's value; lane 0 receives 0
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+// max without the canonicalising self-max that fmaxf costs per operand (no NaN can occur here:
+// finite table entries, and -inf only ever meets finite values)
+__device__ __forceinline__ float max_f32(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+typedef __attribute__((address_space(3))) const float lds_cfloat;
 
 __global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -59,94 +79,93 @@ __global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
   fb.s0 = uni(P.fwd_blocks[blockIdx.x].s0);
   const SeqDesc d = load_desc(P.desc + fb.seq);
   const int L2 = d.len2;
-  const char *Tb = (const char *)smem;                          // kDevTable floats
-  uint32_t *bw = (uint32_t *)(smem + kDevTable * 4);            // fwd_bwords(L2) words
-  int *aw = (int *)(bw + fwd_bwords(L2));                       // fwd_window(L2) byte offsets
+  int *rowb = (int *)(smem + kDevTable * 4);        // fwd_rows(L2) ints, 16-byte aligned
+  int *aw = rowb + fwd_rows(L2);                    // fwd_window(L2) byte offsets
   uint32_t *red = (uint32_t *)(aw + fwd_window(L2));
   for (int i = tid; i < kDevTable; i += 256) ((float *)smem)[i] = P.table_t[i];
   {
-    const uint32_t *src = (const uint32_t *)(P.seq2_pool + d.off2);  // 16-byte aligned, padded to 16
-    const int nsrc = (L2 + 3) / 4;
-    for (int i = tid; i < fwd_bwords(L2); i += 256) bw[i] = i < nsrc ? src[i] : 0u;
+    // a row entry is the LDS address of the table row of that Seq2 residue, so that a table
+    // entry's address is one add: row + 4 * (Seq1 code)
+    const int tbase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const unsigned char *src = P.seq2_pool + d.off2;
+    for (int i = tid; i < fwd_rows(L2); i += 256)
+      rowb[i] = tbase + (i < L2 ? (int)src[i] : kPadCode) * (kRowStride * 4);
   }
-  const int win0 = fb.s0 - 2;
+  const int win0 = fb.s0 - 2;  // Seq1 index of window entry 0
   for (int i = tid; i < fwd_window(L2); i += 256) {
     int64_t idx = (int64_t)win0 + i;
     aw[i] = 4 * ((idx >= 0 && idx < P.len1) ? (int)P.seq1[idx] : kPadCode);
   }
   __syncthreads();
-  const int s = fb.s0 + tid;
+  const int s = fb.s0 + 62 * w + lane - 2;
+  const int *ap = aw + 62 * w + lane;  // ap[j] = 4 * code of Seq1[s + j]
   const float NEG = -INFINITY;
   float a = 0.0f, b = NEG, c = NEG;
-  int a2 = aw[tid], a1 = aw[tid + 1];
-  const int *ap = aw + tid + 2;  // ap[j] = 4 * code of Seq1[s + j]
-#define PSA_T(rowbytes, off) (*(const float *)(Tb + (rowbytes) + (off)))
-  // groups of four steps in which all three states advance: j + 3 <= L2 - 3
-  const int ngroups = (L2 - 2) / 4;
-  int4 o_cur, o_nxt;       // Seq1 offsets of the current / next group
-  uint32_t w_nxt, w_nxt2;  // Seq2 words of the next group / the one after
-  float x_cur[12], x_nxt[12];
-  o_cur = make_int4(ap[0], ap[1], ap[2], ap[3]);
-  o_nxt = make_int4(ap[4], ap[5], ap[6], ap[7]);
-  w_nxt = bw[1];
-  w_nxt2 = bw[2];
-  {
-    const uint32_t w0 = uni(bw[0]);
-    const int r0 = (w0 & 255) * 128, r1 = ((w0 >> 8) & 255) * 128, r2 = ((w0 >> 16) & 255) * 128,
-              r3 = (w0 >> 24) * 128;
-    x_cur[0] = PSA_T(r0, o_cur.x); x_cur[1] = PSA_T(r0, a1); x_cur[2] = PSA_T(r0, a2);
-    x_cur[3] = PSA_T(r1, o_cur.y); x_cur[4] = PSA_T(r1, o_cur.x); x_cur[5] = PSA_T(r1, a1);
-    x_cur[6] = PSA_T(r2, o_cur.z); x_cur[7] = PSA_T(r2, o_cur.y); x_cur[8] = PSA_T(r2, o_cur.x);
-    x_cur[9] = PSA_T(r3, o_cur.w); x_cur[10] = PSA_T(r3, o_cur.z); x_cur[11] = PSA_T(r3, o_cur.y);
+#define PSA_T(addr) (*(lds_cfloat *)(uintptr_t)(unsigned)(addr))
+#define PSA_STEP(x0)                        \
+  {                                         \
+    const float x1_ = lane_shr1(x0);        \
+    const float x2_ = lane_shr1(x1_);       \
+    const float nc_ = max_f32(b, c + x2_);  \
+    const float nb_ = max_f32(a, b + x1_);  \
+    a = a + (x0);                           \
+    b = nb_;                                \
+    c = nc_;                                \
   }
-  for (int g = 0; g < ngroups; ++g) {
-    // fetch for group g+1 (its offsets and word arrived during the previous iteration)
-    const uint32_t wn = uni(w_nxt);
-    const int r0 = (wn & 255) * 128, r1 = ((wn >> 8) & 255) * 128, r2 = ((wn >> 16) & 255) * 128,
-              r3 = (wn >> 24) * 128;
-    x_nxt[0] = PSA_T(r0, o_nxt.x); x_nxt[1] = PSA_T(r0, o_cur.w); x_nxt[2] = PSA_T(r0, o_cur.z);
-    x_nxt[3] = PSA_T(r1, o_nxt.y); x_nxt[4] = PSA_T(r1, o_nxt.x); x_nxt[5] = PSA_T(r1, o_cur.w);
-    x_nxt[6] = PSA_T(r2, o_nxt.z); x_nxt[7] = PSA_T(r2, o_nxt.y); x_nxt[8] = PSA_T(r2, o_nxt.x);
-    x_nxt[9] = PSA_T(r3, o_nxt.w); x_nxt[10] = PSA_T(r3, o_nxt.z); x_nxt[11] = PSA_T(r3, o_nxt.y);
-    // fetch two groups ahead
-    const int jn = 4 * g + 8;
-    const int4 o_nn = make_int4(ap[jn], ap[jn + 1], ap[jn + 2], ap[jn + 3]);
-    const uint32_t w_nn = bw[g + 3];
-    // chain of group g
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float nc = fmaxf(b, c + x_cur[3 * k + 2]);
-      const float nb = fmaxf(a, b + x_cur[3 * k + 1]);
-      a = a + x_cur[3 * k];
-      b = nb;
-      c = nc;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) x_cur[k] = x_nxt[k];
-    a2 = o_cur.z;
-    a1 = o_cur.w;
-    o_cur = o_nxt;
-    o_nxt = o_nn;
-    w_nxt = w_nxt2;
-    w_nxt2 = w_nn;
+  // groups of four steps in which all three states advance: j + 3 <= L2 - 3.  Two groups per
+  // iteration, so the table entries alternate between two register sets without copies.
+  const int ngroups = (L2 - 2) / 4;
+  const int4 *rows4 = (const int4 *)rowb;
+  float xa[4], xb[4];
+  int4 o, r;
+  {
+    const int4 r0 = rows4[0];
+    xa[0] = PSA_T(r0.x + ap[0]);
+    xa[1] = PSA_T(r0.y + ap[1]);
+    xa[2] = PSA_T(r0.z + ap[2]);
+    xa[3] = PSA_T(r0.w + ap[3]);
+  }
+  o = make_int4(ap[4], ap[5], ap[6], ap[7]);
+  r = rows4[1];
+  int g = 0;
+  for (; g + 2 <= ngroups; g += 2) {
+    // table entries of group g+1 (offsets fetched one iteration ago), offsets of group g+2
+    xb[0] = PSA_T(r.x + o.x);
+    xb[1] = PSA_T(r.y + o.y);
+    xb[2] = PSA_T(r.z + o.z);
+    xb[3] = PSA_T(r.w + o.w);
+    int jn = 4 * g + 8;
+    o = make_int4(ap[jn], ap[jn + 1], ap[jn + 2], ap[jn + 3]);
+    r = rows4[g + 2];
+    PSA_STEP(xa[0]) PSA_STEP(xa[1]) PSA_STEP(xa[2]) PSA_STEP(xa[3])
+    // group g+2 and g+3 likewise
+    xa[0] = PSA_T(r.x + o.x);
+    xa[1] = PSA_T(r.y + o.y);
+    xa[2] = PSA_T(r.z + o.z);
+    xa[3] = PSA_T(r.w + o.w);
+    jn += 4;
+    o = make_int4(ap[jn], ap[jn + 1], ap[jn + 2], ap[jn + 3]);
+    r = rows4[g + 3];
+    PSA_STEP(xb[0]) PSA_STEP(xb[1]) PSA_STEP(xb[2]) PSA_STEP(xb[3])
+  }
+  if (g < ngroups) {  // xa holds group g
+    PSA_STEP(xa[0]) PSA_STEP(xa[1]) PSA_STEP(xa[2]) PSA_STEP(xa[3])
   }
   // remaining positions, one at a time
-  const unsigned char *bcode = (const unsigned char *)bw;
   for (int j = 4 * ngroups; j < L2; ++j) {
-    const int a0 = ap[j];
-    const int row = (int)bcode[j] * 128;
-    const float x0 = PSA_T(row, a0), x1 = PSA_T(row, a1), x2 = PSA_T(row, a2);
-    const float nc = fmaxf(b, c + x2);
-    const float nb = (j <= L2 - 2) ? fmaxf(a, b + x1) : NEG;  // one deletion must still follow
-    if (j <= L2 - 3) a = a + x0;                              // two deletions must still follow
+    const float x0 = PSA_T(rowb[j] + ap[j]);
+    const float x1 = lane_shr1(x0);
+    const float x2 = lane_shr1(x1);
+    const float nc = max_f32(b, c + x2);
+    const float nb = (j <= L2 - 2) ? max_f32(a, b + x1) : NEG;  // one deletion must still follow
+    if (j <= L2 - 3) a = a + x0;                                // two deletions must still follow
     b = nb;
     c = nc;
-    a2 = a1;
-    a1 = a0;
   }
+#undef PSA_STEP
 #undef PSA_T
   uint32_t key = 0u;
-  if (s < d.s_end) {
+  if (lane >= 2 && s < d.s_end) {
     P.fs[d.fs_base + (s - d.s_begin)] = c;
     key = f2key(c);
   }
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(256) void psa_collect(ResolveParams P) {
   const FwdBlock fb = P.fwd_blocks[blockIdx.x];
   const SeqDesc d = P.desc[fb.seq];
   const int s = fb.s0 + threadIdx.x;
-  if (s < d.s_end) {
+  if (threadIdx.x < kFwdOffsets && s < d.s_end) {
     const float v = P.fs[d.fs_base + (s - d.s_begin)];
     if (f2key(v) == P.acc[fb.seq].res_key) {
       unsigned idx = atomicAdd(P.nactive, 1u);
@@ -212,18 +231,51 @@ __device__ __forceinline__ void fill_diagonals(float *d0, float2 *d12, const flo
   }
 }
 
+// Serial float32 chains over LDS arrays.  The adds are dependent by nature (the reference's
+// rounding order); what can be hidden is the LDS latency: 8 values are in flight while
+// the previous 8 are added, and the loop is unrolled twice so no register is copied.
+
 // v += d0[from .. to), left to right (every lane computes the same value)
 __device__ __forceinline__ float add_run_d0(const float *d0, int from, int to, float v) {
   int j = from;
   for (; j < to && (j & 3); ++j) v += d0[j];
-  for (; j + 4 <= to; j += 4) {
-    const float4 x = *(const float4 *)(d0 + j);
-    v += x.x;
-    v += x.y;
-    v += x.z;
-    v += x.w;
+  if (j + 8 <= to) {
+    float4 a0 = *(const float4 *)(d0 + j), a1 = *(const float4 *)(d0 + j + 4);
+    for (; j + 24 <= to; j += 16) {
+      const float4 b0 = *(const float4 *)(d0 + j + 8), b1 = *(const float4 *)(d0 + j + 12);
+      v += a0.x; v += a0.y; v += a0.z; v += a0.w; v += a1.x; v += a1.y; v += a1.z; v += a1.w;
+      a0 = *(const float4 *)(d0 + j + 16);
+      a1 = *(const float4 *)(d0 + j + 20);
+      v += b0.x; v += b0.y; v += b0.z; v += b0.w; v += b1.x; v += b1.y; v += b1.z; v += b1.w;
+    }
+    v += a0.x; v += a0.y; v += a0.z; v += a0.w; v += a1.x; v += a1.y; v += a1.z; v += a1.w;
+    j += 8;
   }
   for (; j < to; ++j) v += d0[j];
+  return v;
+}
+
+// v += d12[from .. to).x, left to right (uniform)
+__device__ __forceinline__ float add_run_d1(const float2 *d12, int from, int to, float v) {
+  int j = from;
+  for (; j < to && (j & 1); ++j) v += d12[j].x;
+  if (j + 8 <= to) {
+    const float4 *q = (const float4 *)(d12 + j);  // two positions per 16-byte read
+    float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+    for (; j + 24 <= to; j += 16) {
+      const float4 b0 = q[4], b1 = q[5], b2 = q[6], b3 = q[7];
+      v += a0.x; v += a0.z; v += a1.x; v += a1.z; v += a2.x; v += a2.z; v += a3.x; v += a3.z;
+      a0 = q[8];
+      a1 = q[9];
+      a2 = q[10];
+      a3 = q[11];
+      v += b0.x; v += b0.z; v += b1.x; v += b1.z; v += b2.x; v += b2.z; v += b3.x; v += b3.z;
+      q += 8;
+    }
+    v += a0.x; v += a0.z; v += a1.x; v += a1.z; v += a2.x; v += a2.z; v += a3.x; v += a3.z;
+    j += 8;
+  }
+  for (; j < to; ++j) v += d12[j].x;
   return v;
 }
 
@@ -275,12 +327,32 @@ __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
     float c = -INFINITY;
     v = mine;
     int t = 0;
-    for (; t + 4 <= nsteps; t += 4) {
-      const float2 x0 = dp[t], x1 = dp[t + 1], x2 = dp[t + 2], x3 = dp[t + 3];
-      c = fmaxf(v, c + x0.y); v = v + x0.x;
-      c = fmaxf(v, c + x1.y); v = v + x1.x;
-      c = fmaxf(v, c + x2.y); v = v + x2.x;
-      c = fmaxf(v, c + x3.y); v = v + x3.x;
+    if (nsteps >= 8) {
+      float2 y[8], z[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = dp[k];
+      for (; t + 24 <= nsteps; t += 16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = dp[t + 8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c = fmaxf(v, c + y[k].y);
+          v = v + y[k].x;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = dp[t + 16 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c = fmaxf(v, c + z[k].y);
+          v = v + z[k].x;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c = fmaxf(v, c + y[k].y);
+        v = v + y[k].x;
+      }
+      t += 8;
     }
     for (; t < nsteps; ++t) {
       const float2 x = dp[t];
@@ -331,7 +403,10 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
     const int q = q0 + tid;
     float v = add_run_d0(d0, 0, pstar, 0.0f);  // a_{p*}
     int j = pstar + 1;
-    for (; j < q0; ++j) v += d12[j].x;         // positions every lane of the block consumes
+    if (j < q0) {  // positions every lane of the block consumes
+      v = add_run_d1(d12, j, q0, v);
+      j = q0;
+    }
     float mine = v;
     const int qend = min(q0 + 256, L2);
     for (; j < qend; ++j) {
@@ -342,12 +417,23 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
     const int nsteps = L2 - 1 - q0;
     float c = mine;
     int t = 0;
-    for (; t + 4 <= nsteps; t += 4) {
-      const float y0 = dp[t].y, y1 = dp[t + 1].y, y2 = dp[t + 2].y, y3 = dp[t + 3].y;
-      c += y0;
-      c += y1;
-      c += y2;
-      c += y3;
+    if (nsteps >= 8) {
+      float y[8], z[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = dp[k].y;
+      for (; t + 24 <= nsteps; t += 16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = dp[t + 8 + k].y;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += y[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = dp[t + 16 + k].y;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += z[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c += y[k];
+      t += 8;
     }
     for (; t < nsteps; ++t) c += dp[t].y;
     unsigned long long cand = ~0ull;
@@ -471,7 +557,7 @@ hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hi
 }
 
 static size_t fwd_lds(int max_len2) {
-  return (size_t)kDevTable * 4 + 4 * (size_t)fwd_bwords(max_len2) + 4 * (size_t)fwd_window(max_len2) + 64;
+  return (size_t)kDevTable * 4 + 4 * (size_t)fwd_rows(max_len2) + 4 * (size_t)fwd_window(max_len2) + 64;
 }
 static size_t tie_lds(int max_len2) {
   return (size_t)kDevTable * 4 + 4 * (size_t)tie_d0_len(max_len2) + 8 * (size_t)tie_d12_len(max_len2);
