@@ -28,14 +28,34 @@ constexpr size_t kSlabUnit = 256;                 // bytes: one run of 64 int32
 constexpr size_t kSlabMinUnits = (5u << 20) / 256;  // the largest chunk (64 offsets x (2 x 128 + 1) runs) fits
 constexpr size_t kSlabDefaultMiB = 2048;
 
-template <class T>
-int upload(T **dptr, const std::vector<T> &h) {
-  *dptr = nullptr;
-  if (h.empty()) return PSA_OK;
-  PSA_HIP(hipMalloc((void **)dptr, h.size() * sizeof(T)));
-  PSA_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return PSA_OK;
+// Device block, pinned host block and events of one batch.  A context keeps the bundles of
+// destroyed batches and hands them to new ones, so that scoring batch after batch through
+// psa_score_batch (or Seq2 after Seq2 through the drop-in shim) allocates nothing after the
+// first call; a bundle that is too small is grown.
+struct Bundle {
+  unsigned char *dev = nullptr;
+  size_t dev_cap = 0;
+  unsigned char *pin = nullptr;      // pinned and mapped: upload staging, then the result records
+  unsigned char *pin_dev = nullptr;  // the device's address of pin
+  size_t pin_cap = 0;
+  hipEvent_t ev[5] = {};
+  std::vector<hipEvent_t> pass_ev;  // 4 per slab pass
+};
+
+void bundle_free(Bundle *u) {
+  if (!u) return;
+  if (u->dev) (void)hipFree(u->dev);
+  if (u->pin) (void)hipHostFree(u->pin);
+  for (hipEvent_t e : u->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : u->pass_ev)
+    if (e) (void)hipEventDestroy(e);
+  delete u;
 }
+
+constexpr size_t kMaxCachedBundles = 4;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
@@ -58,6 +78,7 @@ struct psa_ctx {
   bool have_table = false, have_seq1 = false;
   float *d_table_t = nullptr;          // [27][32] floats, [seq2 code][seq1 code]
   unsigned char *d_class_t = nullptr;  // [27][32] class digits
+  std::vector<Bundle *> spare;         // bundles of destroyed batches
 };
 
 struct psa_batch {
@@ -101,6 +122,8 @@ struct psa_batch {
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
   bool acc_ready = false;  // the accumulators were reset after the previous run
+  Bundle *res = nullptr;   // owns every device and pinned pointer above and the events
+  bool upload_in_flight = false;  // the asynchronous upload of the work lists has not been waited for
 };
 
 extern "C" {
@@ -158,6 +181,7 @@ void psa_shutdown(psa_ctx *c) {
   if (c->st_pre) (void)hipStreamDestroy(c->st_pre);
   for (int *p : c->d_slab)
     if (p) (void)hipFree(p);
+  for (Bundle *u : c->spare) bundle_free(u);
   for (hipEvent_t e : c->ev_prep)
     if (e) (void)hipEventDestroy(e);
   delete c;
@@ -217,24 +241,13 @@ void psa_batch_destroy(psa_batch *b) {
         b->ctx->slab_reader_batch[i] = nullptr;
       }
   }
-  if (b->d_pool) (void)hipFree(b->d_pool);
-  if (b->d_desc) (void)hipFree(b->d_desc);
-  if (b->d_acc) (void)hipFree(b->d_acc);
-  if (b->d_counters) (void)hipFree(b->d_counters);
-  if (b->d_chunks) (void)hipFree(b->d_chunks);
-  if (b->d_chunk_best) (void)hipFree(b->d_chunk_best);
-  for (psa_batch::SlabPass &sp : b->passes) {
-    for (int i = 0; i < 2; ++i) {
-      if (sp.ev_b[i]) (void)hipEventDestroy(sp.ev_b[i]);
-      if (sp.ev_e[i]) (void)hipEventDestroy(sp.ev_e[i]);
-    }
+  if (b->res) {
+    if (b->ctx && b->upload_in_flight) (void)hipStreamSynchronize(b->ctx->st_enum);
+    if (b->ctx && b->ctx->spare.size() < kMaxCachedBundles)
+      b->ctx->spare.push_back(b->res);
+    else
+      bundle_free(b->res);
   }
-  if (b->d_fwd) (void)hipFree(b->d_fwd);
-  if (b->d_fs) (void)hipFree(b->d_fs);
-  if (b->d_active) (void)hipFree(b->d_active);
-  if (b->h_out) (void)hipHostFree(b->h_out);
-  for (hipEvent_t e : {b->ev_first, b->ev_last, b->ev_init, b->ev_res, b->ev_res_first})
-    if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -411,22 +424,13 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     W.nunits = (int)base;
   }
 
-  int st = PSA_OK;
   auto fail = [&](int code) {
     psa_batch_destroy(b);
     return code;
   };
-  if ((st = upload(&b->d_pool, pool)) != PSA_OK) return fail(st);
-  if ((st = upload(&b->d_desc, b->desc)) != PSA_OK) return fail(st);
-  if ((st = upload(&b->d_fwd, fwd)) != PSA_OK) return fail(st);
   b->nfwd = (int)fwd.size();
-  if ((st = upload(&b->d_chunks, chunks)) != PSA_OK) return fail(st);
   b->nchunks = (int)chunks.size();
   if (b->nchunks > 0) {
-    if (hipMalloc((void **)&b->d_chunk_best, chunks.size() * sizeof(unsigned long long)) != hipSuccess) {
-      g_err = "hipMalloc(chunk_best) failed";
-      return fail(PSA_ERR_HIP);
-    }
     // slabs of the context: grown when this batch needs more, two once a batch needs two passes
     const int want = 2;
     if (cap_units > c->slab_units || want > c->slab_count) {
@@ -462,23 +466,90 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       return fail(PSA_ERR_HIP);                                       \
     }                                                                 \
   } while (0)
-  if (n > 0) {
-    PSA_HIP_B(hipMalloc((void **)&b->d_acc, (size_t)n * sizeof(psa::SeqAcc)));
-    PSA_HIP_B(hipHostMalloc((void **)&b->h_out, (size_t)n * sizeof(psa_result), hipHostMallocMapped));
-    PSA_HIP_B(hipHostGetDevicePointer((void **)&b->d_out, b->h_out, 0));
-    std::memcpy(b->h_out, b->tmpl.data(), (size_t)n * sizeof(psa_result));
-  }
-  PSA_HIP_B(hipMalloc((void **)&b->d_counters, sizeof(unsigned)));
-  if (fs_total > 0) {
-    PSA_HIP_B(hipMalloc((void **)&b->d_fs, (size_t)fs_total * sizeof(float)));
-    PSA_HIP_B(hipMalloc((void **)&b->d_active, (size_t)fs_total * sizeof(psa::ActiveOffset)));
-  }
-  for (hipEvent_t *e : {&b->ev_first, &b->ev_last, &b->ev_init, &b->ev_res, &b->ev_res_first}) PSA_HIP_B(hipEventCreate(e));
-  for (psa_batch::SlabPass &sp : b->passes) {
-    for (int i = 0; i < 2; ++i) {
-      PSA_HIP_B(hipEventCreate(&sp.ev_b[i]));
-      PSA_HIP_B(hipEventCreate(&sp.ev_e[i]));
+  // One device block and one pinned block per batch.  Uploaded part first (Seq2 pool,
+  // descriptors, forward blocks, chunks), then what only the kernels touch.
+  const size_t o_pool = 0;
+  const size_t o_desc = align_up(o_pool + pool.size(), 256);
+  const size_t o_fwd = align_up(o_desc + b->desc.size() * sizeof(psa::SeqDesc), 256);
+  const size_t o_chunks = align_up(o_fwd + fwd.size() * sizeof(psa::FwdBlock), 256);
+  const size_t upload_bytes = align_up(o_chunks + chunks.size() * sizeof(psa::Chunk), 256);
+  const size_t o_best = upload_bytes;
+  const size_t o_acc = align_up(o_best + chunks.size() * sizeof(unsigned long long), 256);
+  const size_t o_cnt = align_up(o_acc + (size_t)n * sizeof(psa::SeqAcc), 256);
+  const size_t o_fs = align_up(o_cnt + 64, 256);
+  const size_t o_active = align_up(o_fs + (size_t)fs_total * sizeof(float), 256);
+  const size_t dev_bytes = align_up(o_active + (size_t)fs_total * sizeof(psa::ActiveOffset), 256) + 256;
+  const size_t o_out = upload_bytes;  // in the pinned block the records follow the staging area
+  const size_t pin_bytes = o_out + std::max<size_t>(1, (size_t)n) * sizeof(psa_result);
+  {
+    Bundle *u = nullptr;
+    for (size_t i = 0; i < c->spare.size(); ++i)
+      if (c->spare[i]->dev_cap >= dev_bytes && c->spare[i]->pin_cap >= pin_bytes) {
+        u = c->spare[i];
+        c->spare.erase(c->spare.begin() + (long)i);
+        break;
+      }
+    if (!u && !c->spare.empty()) {  // grow the most recent one instead of piling up small ones
+      u = c->spare.back();
+      c->spare.pop_back();
     }
+    if (!u) u = new (std::nothrow) Bundle();
+    if (!u) return fail(PSA_ERR_NOMEM);
+    b->res = u;
+    if (u->dev_cap < dev_bytes) {
+      if (u->dev) (void)hipFree(u->dev);
+      u->dev = nullptr;
+      u->dev_cap = 0;
+      const size_t cap = dev_bytes + dev_bytes / 4;
+      PSA_HIP_B(hipMalloc((void **)&u->dev, cap));
+      u->dev_cap = cap;
+    }
+    if (u->pin_cap < pin_bytes) {
+      if (u->pin) (void)hipHostFree(u->pin);
+      u->pin = nullptr;
+      u->pin_cap = 0;
+      const size_t cap = pin_bytes + pin_bytes / 4;
+      PSA_HIP_B(hipHostMalloc((void **)&u->pin, cap, hipHostMallocMapped));
+      u->pin_cap = cap;
+      PSA_HIP_B(hipHostGetDevicePointer((void **)&u->pin_dev, u->pin, 0));
+    }
+    for (hipEvent_t &e : u->ev)
+      if (!e) PSA_HIP_B(hipEventCreate(&e));
+    while (u->pass_ev.size() < 4 * b->passes.size()) {
+      hipEvent_t e = nullptr;
+      PSA_HIP_B(hipEventCreate(&e));
+      u->pass_ev.push_back(e);
+    }
+    // stage the work lists in pinned memory and send them with one asynchronous copy; the
+    // kernels of the first run are ordered behind it on st_enum
+    if (!pool.empty()) std::memcpy(u->pin + o_pool, pool.data(), pool.size());
+    if (!b->desc.empty()) std::memcpy(u->pin + o_desc, b->desc.data(), b->desc.size() * sizeof(psa::SeqDesc));
+    if (!fwd.empty()) std::memcpy(u->pin + o_fwd, fwd.data(), fwd.size() * sizeof(psa::FwdBlock));
+    if (!chunks.empty()) std::memcpy(u->pin + o_chunks, chunks.data(), chunks.size() * sizeof(psa::Chunk));
+    PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_enum));
+    b->upload_in_flight = true;
+    b->d_pool = u->dev + o_pool;
+    b->d_desc = (psa::SeqDesc *)(u->dev + o_desc);
+    b->d_fwd = (psa::FwdBlock *)(u->dev + o_fwd);
+    b->d_chunks = (psa::Chunk *)(u->dev + o_chunks);
+    b->d_chunk_best = (unsigned long long *)(u->dev + o_best);
+    b->d_acc = (psa::SeqAcc *)(u->dev + o_acc);
+    b->d_counters = (unsigned *)(u->dev + o_cnt);
+    b->d_fs = (float *)(u->dev + o_fs);
+    b->d_active = (psa::ActiveOffset *)(u->dev + o_active);
+    b->h_out = (psa_result *)(u->pin + o_out);
+    if (n > 0) std::memcpy(b->h_out, b->tmpl.data(), (size_t)n * sizeof(psa_result));
+    b->d_out = (psa_result *)(u->pin_dev + o_out);
+    b->ev_first = u->ev[0];
+    b->ev_last = u->ev[1];
+    b->ev_init = u->ev[2];
+    b->ev_res = u->ev[3];
+    b->ev_res_first = u->ev[4];
+    for (size_t k = 0; k < b->passes.size(); ++k)
+      for (int i = 0; i < 2; ++i) {
+        b->passes[k].ev_b[i] = u->pass_ev[4 * k + (size_t)i];
+        b->passes[k].ev_e[i] = u->pass_ev[4 * k + 2 + (size_t)i];
+      }
   }
 #undef PSA_HIP_B
   *out = b;
@@ -655,6 +726,7 @@ int psa_batch_wait(psa_batch *b) {
   // the two record kernels are the last of their streams
   PSA_HIP(hipEventSynchronize(b->ev_last));
   if (b->pending_resolve) PSA_HIP(hipEventSynchronize(b->ev_res));
+  b->upload_in_flight = false;
   b->enum_ms = 0.f;
   b->total_ms = 0.f;
   if (b->pending_timed) {
