@@ -198,6 +198,7 @@ int psa_set_seq1(psa_ctx *c, const char *seq1, int64_t len1) {
     codes[(size_t)i] = ch - 'A';
   }
   PSA_HIP(hipSetDevice(c->device));
+  PSA_HIP(hipDeviceSynchronize());  // runs enqueued and not yet waited for still read the old Seq1
   if (c->d_seq1) {
     PSA_HIP(hipFree(c->d_seq1));
     c->d_seq1 = nullptr;
@@ -217,6 +218,7 @@ int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
   for (int a = 0; a < 26; ++a)
     for (int b = 0; b < 26; ++b) t[b * psa::kRowStride + a] = table[a * 26 + b];
   PSA_HIP(hipSetDevice(c->device));
+  PSA_HIP(hipDeviceSynchronize());  // runs enqueued and not yet waited for still read the old table
   PSA_HIP(hipMemcpy(c->d_table_t, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
   c->have_table = true;
   return PSA_OK;

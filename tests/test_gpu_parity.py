@@ -283,6 +283,37 @@ def test_slab_passes(psa, oracle, monkeypatch):
         c.close()
 
 
+def test_stream_of_batches(psa, oracle):
+    """Several batches of one context enqueued back to back before any is waited for: they share
+    the context's slabs, streams and recycled buffers, and each returns what it returns alone."""
+    seq1, seq2s = synth_problem(92, 2600, [900, 1500, 64, 2000, 333, 1200, 777, 1999])
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    groups = [seq2s[0:3], seq2s[3:4], seq2s[4:8], seq2s[1:2]]
+    alone = [[r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in c.score_batch(g)] for g in groups]
+    for rounds in range(2):
+        batches = [c.batch(g) for g in groups]
+        for rep in range(3):
+            for b in batches:
+                b.enqueue()
+            for b in (batches if rep % 2 == 0 else batches[::-1]):
+                b.wait()
+            got = [[r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in b.results()] for b in batches]
+            assert got == alone
+        batches[2].enqueue()  # destroyed while its run is still pending
+        for b in batches:
+            b.close()
+    table = oracle.comp_matrix(w)
+    check_against_oracle(oracle, seq1, groups[2], table, c.score_batch(groups[2]))
+    # a new Seq1 while nothing is pending, then the same batches again
+    seq1b, _ = synth_problem(93, 2600, [10])
+    c.set_seq1(seq1b)
+    check_against_oracle(oracle, seq1b, groups[0], table, c.score_batch(groups[0]))
+    c.close()
+
+
 def test_long_seq2(psa, ctx, oracle):
     """Seq2 of 4095/4096/8000/8191 characters: the two largest kernel variants."""
     seq1, seq2s = synth_problem(77, 9000, [4095, 4096, 8000, 8191])
