@@ -153,6 +153,36 @@ def test_edge_stress(psa, ctx, oracle):
             check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
 
 
+def test_fuzz_small(psa, ctx, oracle):
+    """Seeded random small problems: lengths on both sides of the 16-, 64- and 256-position steps of
+    the candidate loop, small alphabets (many ties), weights with and without exact float sums."""
+    rng = np.random.default_rng(2024)
+    edge = [2, 3, 4, 15, 16, 17, 18, 31, 32, 33, 47, 48, 49, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193,
+            255, 256, 257, 258, 319, 320, 321]
+    weights = ([2, 1.5, 1.1, 1.3], [1, 1, 1, 1], [3, 0.7, 0.2, 5], [1.1, 1.1, 1.3, 1.3])
+    for it in range(12):
+        alpha = "ACDEFGHIKLMNPQRSTVWY"[:int(rng.integers(1, 21))] if it % 3 else "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+        pick = lambda n: "".join(alpha[i] for i in rng.integers(0, len(alpha), size=n))
+        L1 = int(rng.integers(330, 420))
+        seq1 = pick(L1)
+        lens = [int(x) for x in rng.choice(edge, size=6, replace=False)] + [int(rng.integers(2, L1 + 3)) for _ in range(4)]
+        seq2s = []
+        for L2 in lens:
+            if rng.random() < 0.5 and L2 <= L1:  # a mutated piece of Seq1: a clear winner
+                st = int(rng.integers(0, L1 - L2 + 1))
+                s2 = list(seq1[st:st + L2])
+                for _ in range(max(1, L2 // 10)):
+                    s2[int(rng.integers(0, L2))] = alpha[int(rng.integers(0, len(alpha)))]
+                seq2s.append("".join(s2))
+            else:
+                seq2s.append(pick(L2))
+        w = np.array(weights[it % len(weights)], dtype=np.float32)
+        table = oracle.comp_matrix(w)
+        ctx.set_seq1(seq1)
+        ctx.set_weights(w)
+        check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+
+
 def test_arbitrary_float_table(psa, ctx, oracle):
     rng = np.random.default_rng(9)
     table = rng.normal(0, 3, size=676).astype(np.float32)
