@@ -82,10 +82,10 @@ int main(int argc, char **argv) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  CK(psa::launch_enum_wave(dfg, W, lds, st));
+  CK(psa::launch_enum_wave(dfg, W, lds, st, nullptr, nullptr));
   CK(hipStreamSynchronize(st));
   CK(hipEventRecord(a, st));
-  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, lds, st));
+  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, lds, st, nullptr, nullptr));
   CK(hipEventRecord(b, st));
   CK(hipEventSynchronize(b));
   float ms = 0;
