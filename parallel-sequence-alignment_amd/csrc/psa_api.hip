@@ -393,13 +393,20 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     }
     b->two_slabs = two_slabs;
   }
+  // A small batch runs all its chunks through the pre-pass and locate variant of its longest
+  // Seq2: one launch each instead of one per variant present (a variant works for any shorter
+  // Seq2; on a few thousand chunks the idle threads cost less than the extra launches).
+  const bool one_class = chunks.size() <= 2048;
+  const int top_class = psa::enum_class_of(b->max_len2);
   auto class_bounds = [&](int c0, int c1, int *out) {
     // chunks [c0, c1) are sorted by falling length, so kernel classes fall too:
     // class k owns [out[k + 1], out[k])
     int pos = c0;
     out[psa::kEnumClasses] = c0;
     for (int k = psa::kEnumClasses - 1; k >= 0; --k) {
-      while (pos < c1 && psa::enum_class_of(b->desc[(size_t)chunks[(size_t)pos].seq].len2) == k) ++pos;
+      while (pos < c1 &&
+             (one_class ? top_class : psa::enum_class_of(b->desc[(size_t)chunks[(size_t)pos].seq].len2)) == k)
+        ++pos;
       out[k] = pos;
     }
   };
