@@ -1,0 +1,204 @@
+// psa_mpi: the reference's MPI host program (P/main.c) on top of libpsa_hip, for any number
+// of ranks on any number of nodes, one rank per GPU.
+//
+// Protocol as in the reference: rank 0 reads "input.txt" (P/cFunctions.c:17-37), every rank
+// gets the weights, Seq1 and its share of the Seq2 (P/main.c:54-76, :104-126), scores them,
+// and rank 0 writes one line per Seq2 in input order to "output.txt" and echoes it
+// (P/main.c:79-94).  What changes: the reference is fixed to two ranks (P/main.c:20-24) and
+// splits by count (P/cFunctions.c:49-52, rank 0 takes the first half); here the split
+// balances the candidate counts over all ranks (psa_partition), the sequences travel as one
+// broadcast instead of one MPI_Send per Seq2, and the answers come back as fixed-size
+// records (one MPI_Gatherv) instead of formatted lines.  Buffers are dynamic.
+//
+//   mpiexec -np N psa_mpi [--dry-run] [input.txt [output.txt]]
+//
+// A rank uses GPU (rank on its node) mod (GPUs of the node).  --dry-run does everything but
+// the scoring and prints which rank owns which Seq2: a check of the plumbing without a GPU.
+#include <mpi.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "psa.h"
+
+static bool read_token(FILE *f, std::string &tok) {
+  tok.clear();
+  int c;
+  while ((c = std::fgetc(f)) != EOF && (c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f')) {
+  }
+  if (c == EOF) return false;
+  do tok.push_back((char)c);
+  while ((c = std::fgetc(f)) != EOF && !(c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'));
+  return true;
+}
+
+int main(int argc, char **argv) {
+  MPI_Init(&argc, &argv);
+  int rank = 0, size = 1;
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  MPI_Comm_size(MPI_COMM_WORLD, &size);
+  bool dry = false;
+  std::vector<const char *> pos;
+  for (int i = 1; i < argc; ++i) {
+    if (std::strcmp(argv[i], "--dry-run") == 0)
+      dry = true;
+    else
+      pos.push_back(argv[i]);
+  }
+  const char *in_name = pos.size() > 0 ? pos[0] : "input.txt";    // P/myProto.h:8
+  const char *out_name = pos.size() > 1 ? pos[1] : "output.txt";  // P/myProto.h:9
+  auto t_start = std::chrono::steady_clock::now();
+
+  // rank 0 reads; everything travels in two broadcasts (a header, then the characters)
+  float weights[4] = {0, 0, 0, 0};
+  std::string seq1;
+  std::vector<std::string> seq2;
+  long long header[3] = {0, 0, -1};  // Seq1 length, number of Seq2, status
+  FILE *out = nullptr;
+  if (rank == 0) {
+    FILE *in = std::fopen(in_name, "r");
+    if (!in) {
+      std::printf("Error in opening the file\n");  // P/cFunctions.c:21-24
+    } else {
+      std::string tok;
+      for (int i = 0; i < 4; ++i)
+        if (read_token(in, tok)) weights[i] = std::strtof(tok.c_str(), nullptr);
+      read_token(in, seq1);
+      int count = 0;
+      if (read_token(in, tok)) count = std::atoi(tok.c_str());
+      seq2.resize((size_t)(count > 0 ? count : 0));
+      for (auto &s : seq2) read_token(in, s);  // tokens after the count-th Seq2 are ignored, as in the reference
+      std::fclose(in);
+      out = dry ? nullptr : std::fopen(out_name, "w");
+      if (!dry && !out) {
+        std::printf("Error in opening the file\n");  // P/main.c:46-49
+      } else {
+        header[0] = (long long)seq1.size();
+        header[1] = (long long)seq2.size();
+        header[2] = 0;
+        std::printf("num of seq2 = %d\n", count);  // P/main.c:51
+      }
+    }
+  }
+  MPI_Bcast(header, 3, MPI_LONG_LONG, 0, MPI_COMM_WORLD);
+  if (header[2] != 0) {
+    MPI_Finalize();
+    return 1;
+  }
+  const int n = (int)header[1];
+  MPI_Bcast(weights, 4, MPI_FLOAT, 0, MPI_COMM_WORLD);
+  std::vector<int32_t> len2((size_t)n);
+  if (rank == 0)
+    for (int i = 0; i < n; ++i) len2[(size_t)i] = (int32_t)seq2[(size_t)i].size();
+  if (n > 0) MPI_Bcast(len2.data(), n, MPI_INT32_T, 0, MPI_COMM_WORLD);
+  long long total = header[0];
+  for (int i = 0; i < n; ++i) total += len2[(size_t)i];
+  std::vector<char> blob((size_t)total);
+  if (rank == 0) {
+    size_t at = 0;
+    std::memcpy(blob.data(), seq1.data(), seq1.size());
+    at += seq1.size();
+    for (const auto &s : seq2) {
+      std::memcpy(blob.data() + at, s.data(), s.size());
+      at += s.size();
+    }
+  }
+  for (long long at = 0; at < total; at += (1 << 30)) {  // MPI counts are ints
+    const long long cnt = std::min<long long>(total - at, 1 << 30);
+    MPI_Bcast(blob.data() + at, (int)cnt, MPI_CHAR, 0, MPI_COMM_WORLD);
+  }
+  seq1.assign(blob.data(), (size_t)header[0]);
+
+  // every rank computes the same split
+  std::vector<int32_t> owner((size_t)n, 0);
+  psa_partition(n, len2.data(), (int64_t)seq1.size(), size, owner.data());
+  std::vector<std::string> mine_s;
+  std::vector<int> mine_idx;
+  {
+    size_t at = (size_t)header[0];
+    for (int i = 0; i < n; ++i) {
+      if (owner[(size_t)i] == rank) {
+        mine_s.emplace_back(blob.data() + at, (size_t)len2[(size_t)i]);
+        mine_idx.push_back(i);
+      }
+      at += (size_t)len2[(size_t)i];
+    }
+  }
+  std::vector<char>().swap(blob);
+
+  // score my share on the GPU that goes with my place on this node
+  std::vector<psa_result> mine_r(mine_s.size());
+  int st = PSA_OK;
+  int local = 0;  // my place among the ranks of this node (a collective: every rank takes part)
+  {
+    MPI_Comm node;
+    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
+    MPI_Comm_rank(node, &local);
+    MPI_Comm_free(&node);
+  }
+  if (!dry && !mine_s.empty()) {
+    const int ngpu = psa_device_count();
+    psa_ctx *ctx = nullptr;
+    st = ngpu > 0 ? psa_init(local % ngpu, &ctx) : PSA_ERR_NO_DEVICE;
+    if (st == PSA_OK) st = psa_set_seq1(ctx, seq1.c_str(), (int64_t)seq1.size());
+    if (st == PSA_OK) st = psa_set_weights(ctx, weights);
+    if (st == PSA_OK) {
+      std::vector<const char *> ptr;
+      std::vector<int32_t> lens;
+      for (const auto &s : mine_s) {
+        ptr.push_back(s.c_str());
+        lens.push_back((int32_t)s.size());
+      }
+      st = psa_score_batch(ctx, (int)ptr.size(), ptr.data(), lens.data(), PSA_STAGE_RESOLVE, mine_r.data());
+    }
+    if (st != PSA_OK)
+      std::fprintf(stderr, "psa_mpi: rank %d: %s (%s)\n", rank, psa_strerror(st), psa_last_error_text());
+    psa_shutdown(ctx);
+  }
+  int worst = st;
+  MPI_Allreduce(&st, &worst, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+  if (worst != PSA_OK) {  // the reference exits on device errors, P/cudaFunctions.cu:5-18
+    if (out) std::fclose(out);
+    MPI_Finalize();
+    return EXIT_FAILURE;
+  }
+
+  // records back to rank 0, which knows who owns what
+  std::vector<int> counts((size_t)size, 0), displs((size_t)size, 0);
+  for (int i = 0; i < n; ++i) counts[(size_t)owner[(size_t)i]] += (int)sizeof(psa_result);
+  for (int r = 1; r < size; ++r) displs[(size_t)r] = displs[(size_t)r - 1] + counts[(size_t)r - 1];
+  std::vector<psa_result> all((size_t)n);
+  MPI_Gatherv(mine_r.data(), (int)(mine_r.size() * sizeof(psa_result)), MPI_BYTE, all.data(), counts.data(),
+              displs.data(), MPI_BYTE, 0, MPI_COMM_WORLD);
+  int rc = 0;
+  if (rank == 0) {
+    std::vector<size_t> next((size_t)size);
+    for (int r = 0; r < size; ++r) next[(size_t)r] = (size_t)displs[(size_t)r] / sizeof(psa_result);
+    for (int i = 0; i < n && rc == 0; ++i) {
+      const psa_result &res = all[next[(size_t)owner[(size_t)i]]++];
+      if (dry) {
+        std::printf("Seq2 #%d (%d characters) -> rank %d\n", i + 1, (int)len2[(size_t)i], (int)owner[(size_t)i]);
+        continue;
+      }
+      if (res.status != PSA_OK) {
+        std::fprintf(stderr, "psa_mpi: Seq2 #%d: %s\n", i + 1, psa_strerror(res.status));
+        rc = EXIT_FAILURE;
+        break;
+      }
+      char *line = psa_format_result(&res);
+      std::printf("%s", line);
+      std::fprintf(out, "%s", line);  // P/cFunctions.c:45
+      std::free(line);
+    }
+    if (out) std::fclose(out);
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::printf("Total Time: %1.4f\n", secs);  // P/main.c:97
+  }
+  MPI_Bcast(&rc, 1, MPI_INT, 0, MPI_COMM_WORLD);
+  MPI_Finalize();
+  return rc;
+}

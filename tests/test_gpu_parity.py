@@ -270,6 +270,28 @@ def test_host_program_files(psa, golden, tmp_path):
         assert open(out2).read().splitlines(keepends=True) == want
 
 
+def test_mpi_host_program(psa, golden, tmp_path):
+    """input.txt -> output.txt through the MPI driver with two ranks (both on GPU 0 here)."""
+    import os
+    import subprocess
+    from shutil import which
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "parallel-sequence-alignment_amd", "psa_mpi")
+    mpiexec = which("/opt/conda/bin/mpiexec") or which("mpiexec")
+    if mpiexec is None or not os.path.exists(exe):
+        pytest.skip("no MPI installation: psa_mpi is not built")
+    for name, ranks in (("ref_s_input3.txt", 2), ("ref_input.txt", 2), ("ref_p_input1.txt", 3)):
+        case = [c for c in golden if c["name"] == name][0]
+        inp = os.path.join(root, "tests", "golden", "inputs", name)
+        out = tmp_path / ("mpi_out_" + name)
+        r = subprocess.run([mpiexec, "-np", str(ranks), exe, inp, str(out)], capture_output=True, text=True,
+                           timeout=120, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr + r.stdout
+        want = _expected_lines(psa, case)
+        assert open(out).read().splitlines(keepends=True) == want
+        assert all(line in r.stdout for line in want)
+
+
 def test_config3_shape_small(psa, ctx, oracle):
     """Batch of Seq2 of mixed lengths (every kernel variant in one launch set) against Seq1 = 10000."""
     rng = np.random.default_rng(33)

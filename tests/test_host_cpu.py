@@ -86,3 +86,50 @@ def test_no_gpu_means_loud_failure(psa):
         pytest.skip("a GPU is visible")
     with pytest.raises(psa.PsaError):
         psa.Context(0)
+
+
+def _mpiexec():
+    for cand in ("/opt/conda/bin/mpiexec", "mpiexec"):
+        from shutil import which
+        if which(cand):
+            return which(cand)
+    return None
+
+
+@pytest.mark.parametrize("np_ranks", [1, 2, 3])
+def test_mpi_host_split_dry_run(psa, np_ranks, tmp_path):
+    """psa_mpi without a GPU: rank 0 reads, all ranks agree on the cost-balanced split, rank 0 reports
+    it in input order (the MPI plumbing of the multi-node host program, world sizes 1 to 3)."""
+    import subprocess
+    exe = os.path.join(ROOT, "parallel-sequence-alignment_amd", "psa_mpi")
+    mpiexec = _mpiexec()
+    if mpiexec is None or not os.path.exists(exe):
+        pytest.skip("no MPI installation: psa_mpi is not built")
+    inp = os.path.join(ROOT, "tests", "golden", "inputs", "ref_input.txt")
+    r = subprocess.run([mpiexec, "-np", str(np_ranks), exe, "--dry-run", inp, str(tmp_path / "unused.txt")],
+                       capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "num of seq2 = 4"
+    got = [re.match(r"Seq2 #(\d+) \((\d+) characters\) -> rank (\d+)", l).groups() for l in lines[1:5]]
+    lens = [138, 1202, 466, 377]
+    assert [int(g[0]) for g in got] == [1, 2, 3, 4] and [int(g[1]) for g in got] == lens
+    owner = psa.partition(lens, 1489, np_ranks)
+    assert [int(g[2]) for g in got] == list(owner)
+    assert lines[5].startswith("Total Time: ")
+    assert not (tmp_path / "unused.txt").exists()
+
+
+def test_mpi_host_more_ranks_than_seq2(psa, tmp_path):
+    """Three ranks, two Seq2: the rank without work still takes part in every collective."""
+    import subprocess
+    exe = os.path.join(ROOT, "parallel-sequence-alignment_amd", "psa_mpi")
+    mpiexec = _mpiexec()
+    if mpiexec is None or not os.path.exists(exe):
+        pytest.skip("no MPI installation: psa_mpi is not built")
+    inp = os.path.join(ROOT, "tests", "golden", "inputs", "ref_p_input1.txt")
+    r = subprocess.run([mpiexec, "-np", "3", exe, "--dry-run", inp], capture_output=True, text=True, timeout=60,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "num of seq2 = 2" and len([l for l in lines if l.startswith("Seq2 #")]) == 2
