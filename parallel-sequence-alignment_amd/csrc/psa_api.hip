@@ -38,7 +38,7 @@ struct Bundle {
   unsigned char *pin = nullptr;      // pinned and mapped: upload staging, then the result records
   unsigned char *pin_dev = nullptr;  // the device's address of pin
   size_t pin_cap = 0;
-  hipEvent_t ev[5] = {};
+  hipEvent_t ev[6] = {};
   std::vector<hipEvent_t> pass_ev;  // 4 per slab pass
 };
 
@@ -63,6 +63,7 @@ struct psa_ctx {
   int device = 0;
   int num_cus = 256;
   hipStream_t st_enum = nullptr, st_res = nullptr, st_pre = nullptr;
+  hipStream_t st_copy = nullptr;  // uploads of new batches, beside the runs already enqueued
   // f/g rows of the enumeration stage: the pre-pass fills one slab while the candidate
   // loop reads the other.  Grown on demand, shared by the batches of the context.
   int *d_slab[2] = {nullptr, nullptr};
@@ -118,6 +119,7 @@ struct psa_batch {
   psa_result *d_out = nullptr;  // the device's address of h_out
   // start of the first / end of the last kernel on the enumeration side and on the resolve side
   hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_res_first = nullptr, ev_res = nullptr, ev_init = nullptr;
+  hipEvent_t ev_upload = nullptr;  // the work lists have arrived on the device
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
@@ -159,6 +161,7 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP(hipStreamCreateWithPriority(&c->st_enum, hipStreamNonBlocking, prio_low));
   PSA_HIP(hipStreamCreateWithPriority(&c->st_res, hipStreamNonBlocking, prio_high));
   PSA_HIP(hipStreamCreateWithPriority(&c->st_pre, hipStreamNonBlocking, prio_high));
+  PSA_HIP(hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
   for (hipEvent_t &e : c->ev_prep) PSA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
@@ -179,6 +182,7 @@ void psa_shutdown(psa_ctx *c) {
   if (c->st_enum) (void)hipStreamDestroy(c->st_enum);
   if (c->st_res) (void)hipStreamDestroy(c->st_res);
   if (c->st_pre) (void)hipStreamDestroy(c->st_pre);
+  if (c->st_copy) (void)hipStreamDestroy(c->st_copy);
   for (int *p : c->d_slab)
     if (p) (void)hipFree(p);
   for (Bundle *u : c->spare) bundle_free(u);
@@ -244,7 +248,7 @@ void psa_batch_destroy(psa_batch *b) {
       }
   }
   if (b->res) {
-    if (b->ctx && b->upload_in_flight) (void)hipStreamSynchronize(b->ctx->st_enum);
+    if (b->ctx && b->upload_in_flight) (void)hipStreamSynchronize(b->ctx->st_copy);
     if (b->ctx && b->ctx->spare.size() < kMaxCachedBundles)
       b->ctx->spare.push_back(b->res);
     else
@@ -529,13 +533,15 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       PSA_HIP_B(hipEventCreate(&e));
       u->pass_ev.push_back(e);
     }
-    // stage the work lists in pinned memory and send them with one asynchronous copy; the
-    // kernels of the first run are ordered behind it on st_enum
+    // stage the work lists in pinned memory and send them with one asynchronous copy on the
+    // copy stream (beside whatever runs are enqueued); the first run waits for its event
     if (!pool.empty()) std::memcpy(u->pin + o_pool, pool.data(), pool.size());
     if (!b->desc.empty()) std::memcpy(u->pin + o_desc, b->desc.data(), b->desc.size() * sizeof(psa::SeqDesc));
     if (!fwd.empty()) std::memcpy(u->pin + o_fwd, fwd.data(), fwd.size() * sizeof(psa::FwdBlock));
     if (!chunks.empty()) std::memcpy(u->pin + o_chunks, chunks.data(), chunks.size() * sizeof(psa::Chunk));
-    PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_enum));
+    PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_copy));
+    PSA_HIP_B(hipEventRecord(u->ev[5], c->st_copy));
+    b->ev_upload = u->ev[5];
     b->upload_in_flight = true;
     b->d_pool = u->dev + o_pool;
     b->d_desc = (psa::SeqDesc *)(u->dev + o_desc);
@@ -591,6 +597,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   // only a batch's first run, or one after a failed run, needs the set-up kernel
   const bool init = !b->acc_ready;
   if (init) {
+    if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_upload, 0));
     PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, 1, c->st_enum));
     PSA_HIP(psa::debug_sync("psa_init_acc"));
     if (b->nchunks > 0)
