@@ -63,7 +63,7 @@ def lib():
         L.psa_oracle_fast.argtypes = [u8p, C.c_int64, u8p, C.c_int64, f32p, C.c_int64, C.c_int64,
                                       C.POINTER(OracleResult)]
         L.psa_oracle_forward.argtypes = [u8p, C.c_int64, u8p, C.c_int64, f32p, f32p]
-        L.psa_oracle_fixed_table.argtypes = [f32p, C.c_int64, i32p, C.POINTER(C.c_int)]
+        L.psa_oracle_fixed_table.argtypes = [f32p, C.c_int64, C.c_int, i32p, C.POINTER(C.c_int)]
         L.psa_oracle_enum_brute.argtypes = [u8p, C.c_int64, u8p, C.c_int64, i32p, C.c_int64, C.c_int64,
                                             C.POINTER(OracleEnumResult)]
         L.psa_oracle_enum_fast.argtypes = L.psa_oracle_enum_brute.argtypes
@@ -159,11 +159,15 @@ def counts(seq1, seq2, s, n, k):
     return tuple(out)
 
 
-def fixed_table(table, L2):
+SUM_BITS_F32 = 23  # float32 arithmetic of the enumeration stage (the library's default)
+SUM_BITS_I32 = 29  # int32 arithmetic (PSA_ENUM_I32=1)
+
+
+def fixed_table(table, L2, sum_bits=SUM_BITS_F32):
     t, tp = _f32(table)
     it = np.zeros(676, dtype=np.int32)
     exact = C.c_int()
-    r = lib().psa_oracle_fixed_table(tp, L2, it.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(exact))
+    r = lib().psa_oracle_fixed_table(tp, L2, sum_bits, it.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(exact))
     return r, it, exact.value
 
 

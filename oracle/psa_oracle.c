@@ -316,13 +316,15 @@ int psa_oracle_forward(const uint8_t *seq1, int64_t L1, const uint8_t *seq2, int
 /* ---- fixed-point enumeration score -------------------------------------------
  * The enumerating stage scores a candidate as the exact integer sum of table
  * entries scaled by 2^r and rounded to nearest-even.  r is the largest value in
- * [0,24] with L2 * max|entry| <= 2^29 - 1, which keeps every partial sum and
- * every sum of two partial sums inside int32.  Returns r, or -1 if even r = 0
+ * [0,24] with L2 * max|entry| <= 2^sum_bits - 1.  sum_bits = 29 keeps every partial
+ * sum and every sum of two partial sums inside int32; sum_bits = 23 keeps them
+ * integers of at most 24 bits, which float32 adds exactly (the library's default
+ * arithmetic for this stage).  Returns r, or -1 if even r = 0
  * does not fit; *exact is 0 when the rounding changed some entry, 1 when it
  * changed none, and 2 when in addition L2 * max|entry| < 2^24, so that every
  * partial sum the float32 path forms is representable and the two paths must
  * agree exactly. */
-int psa_oracle_fixed_table(const float *table, int64_t L2, int32_t *itab, int *exact) {
+int psa_oracle_fixed_table(const float *table, int64_t L2, int sum_bits, int32_t *itab, int *exact) {
   int r, i;
   for (r = 24; r >= 0; --r) {
     int64_t mx = 0;
@@ -338,7 +340,7 @@ int psa_oracle_fixed_table(const float *table, int64_t L2, int32_t *itab, int *e
       if (iv < 0) iv = -iv;
       if (iv > mx) mx = iv;
     }
-    if (ok && mx * L2 <= ((int64_t)1 << 29) - 1) break;
+    if (ok && mx * L2 <= ((int64_t)1 << sum_bits) - 1) break;
   }
   if (r < 0) return -1;
   *exact = 1;

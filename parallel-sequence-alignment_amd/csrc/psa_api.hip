@@ -66,6 +66,10 @@ struct psa_ctx {
   hipStream_t st_copy = nullptr;  // uploads of new batches, beside the runs already enqueued
   // f/g rows of the enumeration stage: the pre-pass fills one slab while the candidate
   // loop reads the other.  Grown on demand, shared by the batches of the context.
+  // Arithmetic of the enumeration stage: float32 holding integers of at most 24 bits (default;
+  // the chip issues float add + max3 faster than the integer pair) or int32 with 30-bit values
+  // (PSA_ENUM_I32=1, 6 more fractional bits in the fixed-point table).
+  bool enum_f32 = true;
   int *d_slab[2] = {nullptr, nullptr};
   size_t slab_units = 0;  // capacity of each slab in runs of 64 int32
   int slab_count = 0;
@@ -154,6 +158,7 @@ int psa_init(int device, psa_ctx **out) {
   hipDeviceProp_t prop;
   PSA_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char *e = std::getenv("PSA_ENUM_I32")) c->enum_f32 = std::atoi(e) == 0;
   // The resolve kernels are short and latency-bound; they run beside the long
   // enumeration kernel on a stream of higher priority so their blocks are placed first.
   int prio_low = 0, prio_high = 0;
@@ -321,7 +326,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     d.fs_base = fs_total;
     fs_total += se - sb;
     int exact = -1;
-    d.frac_bits = psa::choose_frac_bits(c->table, L2, &exact);
+    d.frac_bits = psa::choose_frac_bits(c->table, L2, c->enum_f32 ? psa::kSumBitsF32 : psa::kSumBitsI32, &exact);
     if (psa::enum_class_of((int)L2) < 0) d.frac_bits = -1;
     r.enum_frac_bits = d.frac_bits;
     r.enum_exact = d.frac_bits >= 0 ? exact : -1;
@@ -640,7 +645,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
         P.chunk_best = b->d_chunk_best + c0;
         P.nchunks = c1 - c0;
         P.fg = c->d_slab[buf];
-        PSA_HIP(psa::launch_enum_prep(cls, P, c->st_pre, ev_first, cls == last_cls ? c->ev_prep[k & 1] : nullptr));
+        PSA_HIP(psa::launch_enum_prep(cls, P, c->enum_f32, c->st_pre, ev_first, cls == last_cls ? c->ev_prep[k & 1] : nullptr));
         ev_first = nullptr;
       }
       PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[k & 1], 0));
@@ -653,7 +658,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // to three workgroups of 8 waves per CU
       int lds = (resolve || piped) ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
-      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, lds, c->st_enum, sp.ev_b[buf], sp.ev_e[buf]));
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, lds, c->st_enum, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;
       c->slab_reader[buf] = sp.ev_e[buf];
       c->slab_reader_batch[buf] = b;

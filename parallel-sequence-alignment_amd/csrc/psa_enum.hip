@@ -118,7 +118,9 @@ __device__ __forceinline__ void enum_chunk_setup(unsigned char *smem, const Enum
 // ---- pre-pass -----------------------------------------------------------------------
 // Row of offset s in the slab: 64*nruns f values (0 beyond p = L2-2), then 64*nruns g
 // values (q = 0 repeats g[1], q >= L2 repeat g[L2-1]: duplicates of scored candidates).
-template <int NT, int R>
+// With F32 the two values are stored as float32: the scale keeps |f| and |g| at or below 2^24,
+// so the conversion is exact.
+template <int NT, int R, bool F32>
 __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -143,8 +145,10 @@ __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
       const int p = r * NT + tid;
       if (p < npos) {
         const int qq = p < 1 ? 1 : (p > L2 - 1 ? L2 - 1 : p);
-        row[p] = (p <= L2 - 2) ? Es[p] - E1[p + 1] : 0;
-        row[npos + p] = E1[qq] + tot2 - E2[qq + 1];
+        const int fv = (p <= L2 - 2) ? Es[p] - E1[p + 1] : 0;
+        const int gv = E1[qq] + tot2 - E2[qq + 1];
+        row[p] = F32 ? __float_as_int((float)fv) : fv;
+        row[npos + p] = F32 ? __float_as_int((float)gv) : gv;
       }
     }
     row += 2 * npos + 64;  // one run of padding: rows must not start a power of two apart
@@ -152,123 +156,204 @@ __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
 }
 
 // ---- candidate loop -----------------------------------------------------------------
-__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-
 // The two instructions of the candidate loop, pinned: hipcc orders volatile asm
 // statements as written, and the order decides the speed here (see wave_full).
-__device__ __forceinline__ int add_sv(int g, int f) {
-  int t;
-  asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "s"(g), "v"(f));
-  return t;
-}
-__device__ __forceinline__ void max3_acc(int &a, int x, int y) {
-  asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+// Two arithmetic types.  Int32: v_add_u32 + v_max3_i32.  Float32 holding integers of at
+// most 24 bits (every sum exact, so the same candidates win): v_add_f32 + v_max3_f32,
+// which this chip issues about a third faster than the integer pair.  Registers are
+// declared int in both cases; in the float case they hold float32 bit patterns.
+template <bool F32>
+struct Cand;
+template <>
+struct Cand<false> {
+  static constexpr int lowest = INT_MIN;
+  __device__ static __forceinline__ int add_sv(int g, int f) {
+    int t;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "s"(g), "v"(f));
+    return t;
+  }
+  __device__ static __forceinline__ int add_vv(int g, int f) {
+    int t;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(g), "v"(f));
+    return t;
+  }
+  __device__ static __forceinline__ void max3_acc(int &a, int x, int y) {
+    asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+  }
+  // max3 under the lane masks l < I0 (first accumulator) and l < I1 (second)
+  template <int I0, int I1>
+  __device__ static __forceinline__ void max3_masked2(int &a, int x, int y, int &b, int z, int w) {
+    asm volatile(
+        "s_bfm_b64 exec, %6, 0\n\tv_max3_i32 %0, %0, %2, %3\n\ts_bfm_b64 exec, %7, 0\n\t"
+        "v_max3_i32 %1, %1, %4, %5\n\ts_mov_b64 exec, -1"
+        : "+v"(a), "+v"(b)
+        : "v"(x), "v"(y), "v"(z), "v"(w), "n"(I0), "n"(I1));
+  }
+  template <int I0>
+  __device__ static __forceinline__ void max3_masked1(int &a, int x, int y) {
+    asm volatile("s_bfm_b64 exec, %3, 0\n\tv_max3_i32 %0, %0, %1, %2\n\ts_mov_b64 exec, -1"
+                 : "+v"(a)
+                 : "v"(x), "v"(y), "n"(I0));
+  }
+  __device__ static __forceinline__ int add(int a, int b) { return a + b; }
+  __device__ static __forceinline__ int max2(int a, int b) { return max(a, b); }
+  __device__ static __forceinline__ int to_int(int a) { return a; }
+};
+template <>
+struct Cand<true> {
+  static constexpr int lowest = (int)0xce800000u;  // -2^30 as float32: below every score, converts to an int
+  __device__ static __forceinline__ int add_sv(int g, int f) {
+    int t;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(t) : "s"(g), "v"(f));
+    return t;
+  }
+  __device__ static __forceinline__ int add_vv(int g, int f) {
+    int t;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(g), "v"(f));
+    return t;
+  }
+  __device__ static __forceinline__ void max3_acc(int &a, int x, int y) {
+    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+  }
+  template <int I0, int I1>
+  __device__ static __forceinline__ void max3_masked2(int &a, int x, int y, int &b, int z, int w) {
+    asm volatile(
+        "s_bfm_b64 exec, %6, 0\n\tv_max3_f32 %0, %0, %2, %3\n\ts_bfm_b64 exec, %7, 0\n\t"
+        "v_max3_f32 %1, %1, %4, %5\n\ts_mov_b64 exec, -1"
+        : "+v"(a), "+v"(b)
+        : "v"(x), "v"(y), "v"(z), "v"(w), "n"(I0), "n"(I1));
+  }
+  template <int I0>
+  __device__ static __forceinline__ void max3_masked1(int &a, int x, int y) {
+    asm volatile("s_bfm_b64 exec, %3, 0\n\tv_max3_f32 %0, %0, %1, %2\n\ts_mov_b64 exec, -1"
+                 : "+v"(a)
+                 : "v"(x), "v"(y), "n"(I0));
+  }
+  __device__ static __forceinline__ int add(int a, int b) {
+    return __float_as_int(__int_as_float(a) + __int_as_float(b));
+  }
+  __device__ static __forceinline__ int max2(int a, int b) {
+    return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b)));
+  }
+  __device__ static __forceinline__ int to_int(int a) { return (int)__int_as_float(a); }
+};
+
+// 16 values of g (scalar registers) against registers 0..K-1, every lane valid: four
+// blocks of 4 g values; the sums of a block are consumed by the max3 two blocks later
+// (A0 A1 M0 A2 M1 A3 M2 M3).  Left to itself hipcc sometimes emits add, add, max3 on two
+// temporaries, where every max3 waits for the adds right before it: 15 % slower.  Two
+// accumulators per register keep consecutive max3 on different registers.  With all R
+// registers in play a g value is first copied to a vector register (one v_mov_b32 for R
+// adds): adds with a scalar operand issue about 0.6 cycles slower than vector-only ones.
+template <int R, int K, bool F32>
+__device__ __forceinline__ void wave_step16(const int *g, const int (&f)[R], int (&acc)[R][2]) {
+  int t[4][K][4];
+  auto sums = [&](int b) {
+    if (K >= R) {
+      int vg[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vg[i]) : "s"(g[4 * b + i]));
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][0] = Cand<F32>::add_vv(vg[0], f[r]);
+        t[b][r][1] = Cand<F32>::add_vv(vg[1], f[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][2] = Cand<F32>::add_vv(vg[2], f[r]);
+        t[b][r][3] = Cand<F32>::add_vv(vg[3], f[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][0] = Cand<F32>::add_sv(g[4 * b], f[r]);
+        t[b][r][1] = Cand<F32>::add_sv(g[4 * b + 1], f[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        t[b][r][2] = Cand<F32>::add_sv(g[4 * b + 2], f[r]);
+        t[b][r][3] = Cand<F32>::add_sv(g[4 * b + 3], f[r]);
+      }
+    }
+  };
+  auto maxima = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) Cand<F32>::max3_acc(acc[r][0], t[b][r][0], t[b][r][1]);
+#pragma unroll
+    for (int r = 0; r < K; ++r) Cand<F32>::max3_acc(acc[r][1], t[b][r][2], t[b][r][3]);
+  };
+  sums(0);
+  sums(1);
+  maxima(0);
+  sums(2);
+  maxima(1);
+  sums(3);
+  maxima(2);
+  maxima(3);
 }
 
-// q in [qa, qb) (multiples of 64) against registers 0..K-1, every lane valid.  G is
-// wave-uniform, so the 16 values of a step come in with one scalar load and feed
-// v_add_u32 as scalar operands; the other waves of the SIMD cover the load's latency.
-// A step is four blocks of 4 g values; the sums of a block are consumed by v_max3_i32
-// two blocks later (A0 A1 M0 A2 M1 A3 M2 M3).  Left to itself hipcc sometimes emits
-// add, add, max3 on two temporaries, where every max3 waits for the adds right before
-// it: 15 % slower.  Two accumulators per register keep consecutive max3 on different
-// registers.
-template <int R, int K>
+// q in [qa, qb) (multiples of 16) against all R registers.  G is wave-uniform, so the 16
+// values of a step come in with one scalar load; the other waves of the SIMD cover its
+// latency.
+template <int R, bool F32>
 __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int qb, const int (&f)[R],
                                           int (&acc)[R][2]) {
   for (int q = qa; q < qb; q += 16) {
     int g[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) g[i] = G[q + i];
-    int t[4][K][4];
-    auto sums = [&](int b) {
-#pragma unroll
-      for (int r = 0; r < K; ++r) {
-        t[b][r][0] = add_sv(g[4 * b], f[r]);
-        t[b][r][1] = add_sv(g[4 * b + 1], f[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < K; ++r) {
-        t[b][r][2] = add_sv(g[4 * b + 2], f[r]);
-        t[b][r][3] = add_sv(g[4 * b + 3], f[r]);
-      }
-    };
-    auto maxima = [&](int b) {
-#pragma unroll
-      for (int r = 0; r < K; ++r) max3_acc(acc[r][0], t[b][r][0], t[b][r][1]);
-#pragma unroll
-      for (int r = 0; r < K; ++r) max3_acc(acc[r][1], t[b][r][2], t[b][r][3]);
-    };
-    sums(0);
-    sums(1);
-    maxima(0);
-    sums(2);
-    maxima(1);
-    sums(3);
-    maxima(2);
-    maxima(3);
+    wave_step16<R, R, F32>(g, f, acc);
   }
 }
-
-// Register r holds run pc0 + r.  The q run pc0 + K pairs with registers 0..K-1 only
-// (K < R); everything from run pc0 + R on pairs with all R registers.
-template <int R, int K>
-struct WavePhases {
-  __device__ static __forceinline__ void run(const int *__restrict__ G, int pc0, int qend, const int (&f)[R],
-                                             int (&acc)[R][2]) {
-    WavePhases<R, K - 1>::run(G, pc0, qend, f, acc);
-    const int qa = 64 * (pc0 + K);
-    const int qb = (K < R) ? min(qa + 64, qend) : qend;
-    wave_full<R, K>(G, qa, qb, f, acc);
-  }
-};
-template <int R>
-struct WavePhases<R, 0> {
-  __device__ static __forceinline__ void run(const int *__restrict__, int, int, const int (&)[R], int (&)[R][2]) {}
-};
 
 // The q run that coincides with a register's own p run: lane l holds p = q0 + l, so
 // q0 + i pairs only with lanes l < i.  Steps are taken two at a time: for even i the
 // lanes l < i take q0 + i and q0 + i + 1 in one max3; what that leaves out, lane i with
-// q0 + i + 1, is the pair (p, p + 1) of every even lane and is added at the end from a
-// per-lane load.  All R registers share the lane mask of a step.
-template <int R>
-__device__ __forceinline__ void wave_diag(const int *__restrict__ G, int pc0, int nruns, int lane, const int (&f)[R],
-                                          int (&acc)[R][2]) {
-  int gnext[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) gnext[r] = G[(pc0 + r < nruns ? 64 * (pc0 + r) : 0) + lane + 1];
-#pragma unroll 1
-  for (int i0 = 0; i0 < 64; i0 += 8) {
-    int g[R][8];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int base = pc0 + r < nruns ? 64 * (pc0 + r) + i0 : 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) g[r][i] = G[base + i];
+// q0 + i + 1, is the pair (p, p + 1) of every even lane and is added by the caller from a
+// per-lane load.  The sums are formed in every lane; only the max3 runs under the lane
+// mask, which is written to exec and restored inside one asm statement (the wave is
+// whole here: a unit is wave-uniform work).
+template <int I, bool F32>
+__device__ __forceinline__ void diag_steps(const int *g, int f, int (&acc)[2]) {
+  if constexpr (I < 64) {
+    const int t0 = Cand<F32>::add_sv(g[I], f), t1 = Cand<F32>::add_sv(g[I + 1], f);
+    if constexpr (I + 2 < 64) {
+      const int t2 = Cand<F32>::add_sv(g[I + 2], f), t3 = Cand<F32>::add_sv(g[I + 3], f);
+      Cand<F32>::template max3_masked2<I, I + 2>(acc[0], t0, t1, acc[1], t2, t3);
+    } else {
+      Cand<F32>::template max3_masked1<I>(acc[0], t0, t1);
     }
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      if (lane < i0 + i) {
-        int t[R][2];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          t[r][0] = add_sv(g[r][i], f[r]);
-          t[r][1] = add_sv(g[r][i + 1], f[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) max3_acc(acc[r][(i >> 1) & 1], t[r][0], t[r][1]);
-      }
-    }
-  }
-  if ((lane & 1) == 0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r][0] = max(acc[r][0], f[r] + gnext[r]);
+    diag_steps<I + 4, F32>(g, f, acc);
   }
 }
 
+// The q runs of the level's own R runs of p: run pc0 + J pairs with every lane of
+// registers 0..J-1 and with register J along the diagonal.  Its 64 values of g are
+// fetched with one group of scalar loads and stay in scalar registers for all of that.
+template <int R, int J, bool F32>
+struct WaveOwn {
+  __device__ static __forceinline__ void run(const int *__restrict__ G, int pc0, int nruns, const int (&f)[R],
+                                             int (&acc)[R][2]) {
+    WaveOwn<R, J - 1, F32>::run(G, pc0, nruns, f, acc);
+    if (pc0 + J < nruns) {
+      int g[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) g[i] = G[64 * (pc0 + J) + i];
+      if constexpr (J > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wave_step16<R, J, F32>(g + 16 * c, f, acc);
+      }
+      diag_steps<2, F32>(g, f[J], acc[J]);
+    }
+  }
+};
+template <int R, bool F32>
+struct WaveOwn<R, -1, F32> {
+  __device__ static __forceinline__ void run(const int *__restrict__, int, int, const int (&)[R], int (&)[R][2]) {}
+};
+
 // One unit: sub-run j of chunk c at level w (positions p in [256 w, 256 w + 256)).
-template <int R>
+template <int R, bool F32>
 __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const WaveParams &P, int u, int lane) {
   int w = 0;
 #pragma unroll
@@ -290,7 +375,7 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
-    acc[r][0] = acc[r][1] = INT_MIN;
+    acc[r][0] = acc[r][1] = Cand<F32>::lowest;
   }
   for (int i = r0; i < r1; ++i) {
     int f[R];
@@ -302,8 +387,15 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
       for (int r = 0; r < R; ++r) fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
     }
-    WavePhases<R, R>::run(G, pc0, qlast, f, acc);
-    wave_diag<R>(G, pc0, nruns, lane, f, acc);
+    int gnext[R];  // g[p + 1] per lane: the diagonal's left-over pairs
+#pragma unroll
+    for (int r = 0; r < R; ++r) gnext[r] = G[(pc0 + r < nruns ? 64 * (pc0 + r) : 0) + lane + 1];
+    wave_full<R, F32>(G, 64 * (pc0 + R), qlast, f, acc);
+    WaveOwn<R, R - 1, F32>::run(G, pc0, nruns, f, acc);
+    if ((lane & 1) == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r][0] = Cand<F32>::max2(acc[r][0], Cand<F32>::add(f[r], gnext[r]));
+    }
   }
   // best fixed-point score of this unit and the smallest p attaining it
   int bestv = INT_MIN;
@@ -311,7 +403,7 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int p = 64 * (pc0 + r) + lane;
-    const int a = max(acc[r][0], acc[r][1]);
+    const int a = Cand<F32>::to_int(Cand<F32>::max2(acc[r][0], acc[r][1]));
     if (p <= L2 - 2 && a > bestv) {
       bestv = a;
       bestp = (uint32_t)p;
@@ -334,11 +426,11 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 // then hold their first, largest units until every other wave has run out of work.)
 // The launch may ask for LDS it never uses: 41 KB pins three workgroups per CU, which
 // leaves wave slots, registers and LDS for the short kernels of the other streams.
-template <int R>
+template <int R, bool F32>
 __global__ __launch_bounds__(512, 8) void psa_enum_wave(const int *__restrict__ fg, WaveParams P) {
   const int lane = threadIdx.x & 63;
   const int u = uni((int)(blockIdx.x * 8 + (threadIdx.x >> 6)));
-  if (u < P.nunits) wave_unit<R>(fg, P, u, lane);
+  if (u < P.nunits) wave_unit<R, F32>(fg, P, u, lane);
 }
 
 // waves per SIMD the locate kernel's register budget is sized for
@@ -409,8 +501,11 @@ static hipError_t set_lds_attr() {
   using L = EnumLds<NT, R>;
   static bool attr_done = false;
   if (attr_done) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     L::total);
+  hipError_t e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          L::total);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)psa_enum_locate<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
   if (e != hipSuccess) return e;
@@ -419,11 +514,16 @@ static hipError_t set_lds_attr() {
 }
 
 template <int NT, int R>
-static hipError_t launch_prep_t(const EnumParams &P, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+static hipError_t launch_prep_t(const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
+                                hipEvent_t ev_stop) {
   hipError_t e = set_lds_attr<NT, R>();
   if (e != hipSuccess) return e;
-  hipExtLaunchKernelGGL((psa_enum_prep<NT, R>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st, ev_start,
-                        ev_stop, 0, P);
+  if (f32)
+    hipExtLaunchKernelGGL((psa_enum_prep<NT, R, true>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st,
+                          ev_start, ev_stop, 0, P);
+  else
+    hipExtLaunchKernelGGL((psa_enum_prep<NT, R, false>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st,
+                          ev_start, ev_stop, 0, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_enum_prep");
 }
@@ -437,11 +537,15 @@ static hipError_t launch_locate_t(const EnumParams &P, int grid, hipStream_t st)
   return debug_sync("psa_enum_locate");
 }
 
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, int lds_bytes, hipStream_t st, hipEvent_t ev_start,
-                            hipEvent_t ev_stop) {
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int lds_bytes, hipStream_t st,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
   // the events ride on the kernel's own dispatch packet: no marker packets before or after it
-  hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st, ev_start,
-                        ev_stop, 0, fg, P);
+  if (f32)
+    hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, true>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st,
+                          ev_start, ev_stop, 0, fg, P);
+  else
+    hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, false>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st,
+                          ev_start, ev_stop, 0, fg, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return debug_sync("psa_enum_wave");
@@ -471,15 +575,16 @@ int enum_class_lds_bytes(int c) {
 
 int enum_class_threads(int c) { return c < 2 ? 256 : (c < 4 ? 512 : 1024); }
 
-hipError_t launch_enum_prep(int cls, const EnumParams &P, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
+                            hipEvent_t ev_stop) {
   if (P.nchunks <= 0) return hipSuccess;
   switch (cls) {
-    case 0: return launch_prep_t<256, 1>(P, st, ev_start, ev_stop);
-    case 1: return launch_prep_t<256, 2>(P, st, ev_start, ev_stop);
-    case 2: return launch_prep_t<512, 2>(P, st, ev_start, ev_stop);
-    case 3: return launch_prep_t<512, 4>(P, st, ev_start, ev_stop);
-    case 4: return launch_prep_t<1024, 4>(P, st, ev_start, ev_stop);
-    case 5: return launch_prep_t<1024, 8>(P, st, ev_start, ev_stop);
+    case 0: return launch_prep_t<256, 1>(P, f32, st, ev_start, ev_stop);
+    case 1: return launch_prep_t<256, 2>(P, f32, st, ev_start, ev_stop);
+    case 2: return launch_prep_t<512, 2>(P, f32, st, ev_start, ev_stop);
+    case 3: return launch_prep_t<512, 4>(P, f32, st, ev_start, ev_stop);
+    case 4: return launch_prep_t<1024, 4>(P, f32, st, ev_start, ev_stop);
+    case 5: return launch_prep_t<1024, 8>(P, f32, st, ev_start, ev_stop);
     default: return hipErrorInvalidValue;
   }
 }

@@ -63,11 +63,13 @@ void build_table_from_weights(const float w[4], float out[PSA_TABLE_SIZE]) {
 }
 
 // Fixed-point scale of the enumeration stage: the largest r in [0,24] such that
-// len2 * max|round(entry * 2^r)| <= 2^29 - 1.  Then any prefix sum is below 2^29
-// in magnitude, the two halves f and g of a candidate score below 2^30, and
-// their sum inside int32.
-int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int *exact_level) {
-  const int64_t limit = (int64_t(1) << 29) - 1;
+// len2 * max|round(entry * 2^r)| <= 2^sum_bits - 1.  Then any prefix sum is below
+// 2^sum_bits in magnitude and the two halves f and g of a candidate score (each a
+// sum or difference of two prefix sums) below 2^(sum_bits + 1).  sum_bits = 29 keeps f, g
+// and f + g inside int32; sum_bits = 23 keeps them integers of at most 24 bits, which
+// float32 holds and adds exactly.
+int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int sum_bits, int *exact_level) {
+  const int64_t limit = (int64_t(1) << sum_bits) - 1;
   int r = 24;
   for (; r >= 0; --r) {
     int64_t mx = 0;

@@ -60,7 +60,9 @@ struct ActiveOffset {
 
 int residue_class_code(int a, int b);
 void build_table_from_weights(const float w[4], float out[PSA_TABLE_SIZE]);
-int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int *exact_level);
+constexpr int kSumBitsI32 = 29;  // prefix-sum width of the enumeration stage in int32 arithmetic
+constexpr int kSumBitsF32 = 23;  // and in float32 arithmetic (integers of at most 24 bits)
+int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int sum_bits, int *exact_level);
 void nk_of_mutant(int64_t t, int len2, int *n, int *k);
 int64_t mutant_of_nk(int n, int k, int len2);
 int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner);

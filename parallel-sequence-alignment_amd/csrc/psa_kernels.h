@@ -75,9 +75,12 @@ int enum_class_threads(int c);
 hipError_t debug_sync(const char *what);
 hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hipStream_t st);
 // ev_start / ev_stop (may be null) are attached to the kernel's dispatch, not recorded beside it
-hipError_t launch_enum_prep(int cls, const EnumParams &P, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, int lds_bytes, hipStream_t st, hipEvent_t ev_start,
+// f32: the slab holds float32 values and the candidate loop adds and compares in float32
+// (exact: the scale keeps every value an integer of at most 24 bits); otherwise int32
+hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
                             hipEvent_t ev_stop);
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int lds_bytes, hipStream_t st,
+                            hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st);
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,
                           hipEvent_t ev_start);

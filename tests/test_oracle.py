@@ -152,11 +152,16 @@ def test_fast_offset_subranges(oracle):
 
 def test_fixed_table(oracle):
     t = oracle.comp_matrix(np.array([2, 1.5, 1, 1.25], dtype=np.float32))
-    r, it, exact = oracle.fixed_table(t, 2000)
-    assert exact == 2 and r >= 2 and int(np.abs(it).max()) * 2000 <= 2 ** 29 - 1
+    for bits in (oracle.SUM_BITS_F32, oracle.SUM_BITS_I32):
+        r, it, exact = oracle.fixed_table(t, 2000, bits)
+        assert exact == 2 and r >= 2 and int(np.abs(it).max()) * 2000 <= 2 ** bits - 1
     t = oracle.comp_matrix(np.array([2, 1.5, 1.1, 1.3], dtype=np.float32))
-    r, it, exact = oracle.fixed_table(t, 2000)
+    r, it, exact = oracle.fixed_table(t, 2000, oracle.SUM_BITS_I32)
     assert not exact and r == 17
+    r, it, exact = oracle.fixed_table(t, 2000)
+    assert not exact and r == 11 and int(np.abs(it).max()) == 4096
+    r, it, exact = oracle.fixed_table(t, 8000)
+    assert not exact and r == 9
     r, it, exact = oracle.fixed_table(t * np.float32(1e9), 2000)
     assert r == -1
 

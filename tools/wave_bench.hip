@@ -2,12 +2,13 @@
 // rest of a run around it.
 // Build: hipcc -O3 --offload-arch=gfx950 -I../include -o wave_bench wave_bench.hip \
 //        -L../parallel-sequence-alignment_amd -lpsa_hip -Wl,-rpath,'$ORIGIN/../parallel-sequence-alignment_amd'
-// Run:   ./wave_bench [offsets] [len2] [enum_ns] [sub_log2] [reps] [lds_bytes]
+// Run:   ./wave_bench [offsets] [len2] [enum_ns] [sub_log2] [reps] [lds_bytes] [f32: 1 (default) or 0]
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../parallel-sequence-alignment_amd/csrc/psa_kernels.h"
@@ -28,6 +29,7 @@ int main(int argc, char **argv) {
   const int sub_log2 = argc > 4 ? std::atoi(argv[4]) : 3;
   const int reps = argc > 5 ? std::atoi(argv[5]) : 20;
   const int lds = argc > 6 ? std::atoi(argv[6]) : 0;
+  const bool f32 = argc > 7 ? std::atoi(argv[7]) != 0 : true;
   const int nruns = (len2 + 63) / 64, stride = 128 * nruns + 64;
   const int levels = (nruns + psa::kEnumWaveRuns - 1) / psa::kEnumWaveRuns;
   const int per = std::min(ens << sub_log2, psa::kEnumMaxNs);
@@ -64,7 +66,15 @@ int main(int argc, char **argv) {
   psa::SeqAcc *dacc;
   unsigned long long *dbest;
   CK(hipMalloc((void **)&dfg, h.size() * 4));
-  CK(hipMemcpy(dfg, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<int> up(h);
+    if (f32)  // the float32 loop reads float32 bit patterns (|values| <= 10^5: exact)
+      for (int &v : up) {
+        const float fv = (float)v;
+        std::memcpy(&v, &fv, 4);
+      }
+    CK(hipMemcpy(dfg, up.data(), up.size() * 4, hipMemcpyHostToDevice));
+  }
   CK(hipMalloc((void **)&dch, chunks.size() * sizeof(psa::Chunk)));
   CK(hipMemcpy(dch, chunks.data(), chunks.size() * sizeof(psa::Chunk), hipMemcpyHostToDevice));
   CK(hipMalloc((void **)&dd, sizeof d));
@@ -82,10 +92,10 @@ int main(int argc, char **argv) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  CK(psa::launch_enum_wave(dfg, W, lds, st, nullptr, nullptr));
+  CK(psa::launch_enum_wave(dfg, W, f32, lds, st, nullptr, nullptr));
   CK(hipStreamSynchronize(st));
   CK(hipEventRecord(a, st));
-  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, lds, st, nullptr, nullptr));
+  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, f32, lds, st, nullptr, nullptr));
   CK(hipEventRecord(b, st));
   CK(hipEventSynchronize(b));
   float ms = 0;
@@ -110,7 +120,7 @@ int main(int argc, char **argv) {
   }
   const int gv = (int)((uint32_t)(acc.enum_key >> 32) ^ 0x80000000u), gp = (int)(0xffffffffu - (uint32_t)acc.enum_key);
   const double cand = (double)rows * ((double)len2 * (len2 - 1) / 2);
-  std::printf("offsets=%d len2=%d enum_ns=%d sub_log2=%d units=%d lds=%d  %.4f ms  %.3e cand/s  frac=%.3f  check=%s\n", rows,
+  std::printf("%s offsets=%d len2=%d enum_ns=%d sub_log2=%d units=%d lds=%d  %.4f ms  %.3e cand/s  frac=%.3f  check=%s\n", f32 ? "f32" : "i32", rows,
               len2, ens, sub_log2, W.nunits, lds, ms, cand / (ms * 1e-3), 2 * cand / (ms * 1e-3) / 78.6432e12,
               (gv == (int)bv && gp == bp) ? "ok" : "FAIL");
   return !(gv == (int)bv && gp == bp);
