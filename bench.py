@@ -30,8 +30,9 @@ sys.path.insert(0, os.path.join(ROOT, "parallel-sequence-alignment_amd"))
 ALPHA20 = "ACDEFGHIKLMNPQRSTVWY"
 WEIGHTS = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)  # the reference's input.txt weights
 
-# INT32 VALU peak of one MI355X: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz
-# (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues in 2 cycles, max clock 2400 MHz)
+# 32-bit VALU peak of one MI355X (int32 or float32 add): 256 CUs x 4 SIMDs x 32 lanes per clock
+# x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues in 2 cycles, max
+# clock 2400 MHz)
 PEAK_INT32_LANE_OPS = 256 * 4 * 32 * 2.4e9
 OPS_PER_CANDIDATE = 2  # one add (f[p] + g[q]) and one max per (offset, mutant) candidate
 
@@ -200,13 +201,26 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # Duration of the candidate-loop kernel on its own.  In the timed region above two of its
+    # launches (consecutive steps) share the GPU, so the dispatch events of one launch span more
+    # than its own work; here every step is awaited before the next is launched (its own
+    # pre-pass, resolve chain and records still run beside it).  Outside the timed region.
+    iso_enum_ms = iso_gpu_ms = 0.0
+    n_iso = 0 if args.sync_steps else max(1, min(args.steps, 10))
+    for _ in range(n_iso):
+        batch.launch(stages)
+        em, tm = batch.timing()
+        iso_enum_ms += em
+        iso_gpu_ms += tm
+    torch.cuda.synchronize()
+
     res = batch.results()
     bad = [r.status for r in res if r.status != 0]
     if bad:
         raise SystemExit("workload has invalid Seq2: %r" % bad)
     cand_rank = sum(r.candidates for r in res)
     if dist is not None:
-        t = torch.tensor([elapsed, float(cand_rank), enum_ms], dtype=torch.float64, device=cdev)
+        t = torch.tensor([elapsed, float(cand_rank)], dtype=torch.float64, device=cdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -223,14 +237,17 @@ def main():
         cand_total = float(cand_rank)
 
     if rank == 0:
+        enum_dtype = "i32" if os.environ.get("PSA_ENUM_I32", "0") not in ("", "0") else "f32 (24-bit integers)"
         value = cand_total * args.steps / elapsed
         out = {
             "metric": "scored (offset,mutant) candidates/sec",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "gpu_ms_per_step": gpu_ms / args.steps,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            # first kernel start to last kernel end of one step run on its own (HIP events)
+            "gpu_ms_per_step_alone": (iso_gpu_ms / n_iso) if n_iso else gpu_ms / args.steps,
             "higher_is_better": True,
             "scaling": "strong" if args.config == "c4" else "weak",
-            "vs_baseline": None, "dtype": "i32 (enumeration) + f32 (exact resolve)", "data": "synthetic"
+            "vs_baseline": None, "dtype": enum_dtype + " (enumeration) + f32 (exact resolve)", "data": "synthetic"
             if args.config != "c1" else "reference sample input",
             "config": {"workload": name, "stages": args.stages, "weights": [float(x) for x in WEIGHTS],
                        "candidates_per_step": cand_total, "seed": "2 + 1000*rank"},
@@ -239,26 +256,34 @@ def main():
                               "enum_k": res[0].enum_k, "enum_offset": res[0].enum_offset},
         }
         if stages & psa_amd.STAGE_ENUMERATE and enum_ms > 0:
-            kern_s = enum_ms / 1e3 / args.steps  # this rank's average enumeration-kernel time per step
+            # this rank's average candidate-loop kernel time per step, launches not sharing the GPU
+            kern_s = (iso_enum_ms / n_iso if n_iso else enum_ms / args.steps) / 1e3
             achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
             # slab rows the candidate loop reads: 4-byte f and g per (offset, position), once each
             slab_bytes = sum(8.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
                              for s2, r in zip(seq2s, res) if r.candidates > 0) if rng is None else \
                 8.0 * len(seq2s[0]) * (rng[1] - rng[0])
             out["roofline"] = {
-                "bound": "valu-int32", "kernel": "psa_enum_wave",
+                "bound": "valu-32bit", "kernel": "psa_enum_wave",
                 "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
                 "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config, slab_bytes / 2),
                 "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs, plus the half of "
                                 "the f-row reads that FETCH_SIZE does not count; Infinity-Cache hits included)",
                 "kernel_ms": kern_s * 1e3,
+                # the same launch inside the timed region, where it shares the GPU with the launch
+                # of the step before or after it (null with --sync-steps: no sharing)
+                "kernel_ms_pipelined": None if args.sync_steps else enum_ms / args.steps,
+                # the same fraction with the whole step in the denominator (pre-pass, locate,
+                # records and every gap included)
+                "step_frac": cand_rank * OPS_PER_CANDIDATE * args.steps / elapsed / PEAK_INT32_LANE_OPS,
                 "hbm_bytes_algorithmic": slab_bytes,
                 "hbm_frac": slab_bytes / kern_s / 8.0e12,
-                "note": "2 int32 lane-ops (add + max) per candidate x candidates per step / HIP-event time of "
-                        "the candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
-                        "their stream; the kernel reads 8 bytes of slab per (offset, position) against "
-                        "L2/2 candidates each (hbm_frac of the 8 TB/s peak), so INT32 VALU issue bounds it, "
-                        "not HBM or MFMA",
+                "note": "2 lane-ops (add + max) per candidate x candidates per step / HIP-event time of the "
+                        "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
+                        "their stream, measured on steps launched one at a time after the timed region "
+                        "(inside it two launches share the GPU: kernel_ms_pipelined); the kernel reads 8 bytes "
+                        "of slab per (offset, position) against L2/2 candidates each (hbm_frac of the 8 TB/s "
+                        "peak), so 32-bit VALU issue bounds it, not HBM or MFMA",
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(seq1, seq2s[0])

@@ -38,7 +38,7 @@ struct Bundle {
   unsigned char *pin = nullptr;      // pinned and mapped: upload staging, then the result records
   unsigned char *pin_dev = nullptr;  // the device's address of pin
   size_t pin_cap = 0;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> pass_ev;  // 4 per slab pass
 };
 
@@ -62,10 +62,13 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct psa_ctx {
   int device = 0;
   int num_cus = 256;
-  hipStream_t st_enum = nullptr, st_res = nullptr, st_pre = nullptr;
-  hipStream_t st_copy = nullptr;  // uploads of new batches, beside the runs already enqueued
-  // f/g rows of the enumeration stage: the pre-pass fills one slab while the candidate
-  // loop reads the other.  Grown on demand, shared by the batches of the context.
+  // Four streams, all of one priority.  Candidate loops alternate between st_enum[0] and
+  // st_enum[1]: consecutive ones share nothing (each has its slab and its copy of the
+  // accumulators), so the next one fills the CUs that the draining one leaves idle; locate and
+  // the enumeration half of the records follow their candidate loop on its stream.  st_res
+  // carries the float32 resolve chain, st_pre the pre-passes and the uploads of new batches.
+  hipStream_t st_enum[2] = {nullptr, nullptr}, st_res = nullptr, st_pre = nullptr;
+  int enum_streams = 2, enum_flip = 0;
   // Arithmetic of the enumeration stage: float32 holding integers of at most 24 bits (default;
   // the chip issues float add + max3 faster than the integer pair) or int32 with 30-bit values
   // (PSA_ENUM_I32=1, 6 more fractional bits in the fixed-point table).
@@ -124,6 +127,12 @@ struct psa_batch {
   // start of the first / end of the last kernel on the enumeration side and on the resolve side
   hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_res_first = nullptr, ev_res = nullptr, ev_init = nullptr;
   hipEvent_t ev_upload = nullptr;  // the work lists have arrived on the device
+  // The enumeration accumulators (SeqAcc::enum_*, the per-chunk keys) exist twice and runs
+  // alternate between the copies, so that the candidate loop of a run can start while locate
+  // and the records of the run before are still reading theirs.
+  int acc_par = 0;
+  hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset
+  bool tail_recorded[2] = {false, false};
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
@@ -159,14 +168,16 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PSA_ENUM_I32")) c->enum_f32 = std::atoi(e) == 0;
-  // The resolve kernels are short and latency-bound; they run beside the long
-  // enumeration kernel on a stream of higher priority so their blocks are placed first.
-  int prio_low = 0, prio_high = 0;
-  PSA_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-  PSA_HIP(hipStreamCreateWithPriority(&c->st_enum, hipStreamNonBlocking, prio_low));
-  PSA_HIP(hipStreamCreateWithPriority(&c->st_res, hipStreamNonBlocking, prio_high));
-  PSA_HIP(hipStreamCreateWithPriority(&c->st_pre, hipStreamNonBlocking, prio_high));
-  PSA_HIP(hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
+  // Every stream has the same priority.  (With the short kernels' streams at a higher priority
+  // than the candidate loop's, a stream that waited for a candidate loop not yet dispatched hung
+  // the run: measured.)  The short kernels find room beside the candidate loops because those
+  // cap themselves at three workgroups per CU (see enqueue_run), not through priority.  Four
+  // streams, because a process has four hardware queues here: a fifth stream shares a queue
+  // with another one and runs in order with it.
+  for (hipStream_t &st : c->st_enum) PSA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  PSA_HIP(hipStreamCreateWithFlags(&c->st_res, hipStreamNonBlocking));
+  PSA_HIP(hipStreamCreateWithFlags(&c->st_pre, hipStreamNonBlocking));
+  if (const char *e = std::getenv("PSA_ENUM_STREAMS")) c->enum_streams = std::atoi(e) == 1 ? 1 : 2;  // tuning aid
   for (hipEvent_t &e : c->ev_prep) PSA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
@@ -184,10 +195,10 @@ void psa_shutdown(psa_ctx *c) {
   if (c->d_seq1) (void)hipFree(c->d_seq1);
   if (c->d_table_t) (void)hipFree(c->d_table_t);
   if (c->d_class_t) (void)hipFree(c->d_class_t);
-  if (c->st_enum) (void)hipStreamDestroy(c->st_enum);
+  for (hipStream_t st : c->st_enum)
+    if (st) (void)hipStreamDestroy(st);
   if (c->st_res) (void)hipStreamDestroy(c->st_res);
   if (c->st_pre) (void)hipStreamDestroy(c->st_pre);
-  if (c->st_copy) (void)hipStreamDestroy(c->st_copy);
   for (int *p : c->d_slab)
     if (p) (void)hipFree(p);
   for (Bundle *u : c->spare) bundle_free(u);
@@ -253,7 +264,7 @@ void psa_batch_destroy(psa_batch *b) {
       }
   }
   if (b->res) {
-    if (b->ctx && b->upload_in_flight) (void)hipStreamSynchronize(b->ctx->st_copy);
+    if (b->ctx && b->upload_in_flight) (void)hipStreamSynchronize(b->ctx->st_pre);
     if (b->ctx && b->ctx->spare.size() < kMaxCachedBundles)
       b->ctx->spare.push_back(b->res);
     else
@@ -492,8 +503,8 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   const size_t o_chunks = align_up(o_fwd + fwd.size() * sizeof(psa::FwdBlock), 256);
   const size_t upload_bytes = align_up(o_chunks + chunks.size() * sizeof(psa::Chunk), 256);
   const size_t o_best = upload_bytes;
-  const size_t o_acc = align_up(o_best + chunks.size() * sizeof(unsigned long long), 256);
-  const size_t o_cnt = align_up(o_acc + (size_t)n * sizeof(psa::SeqAcc), 256);
+  const size_t o_acc = align_up(o_best + 2 * chunks.size() * sizeof(unsigned long long), 256);
+  const size_t o_cnt = align_up(o_acc + 2 * (size_t)n * sizeof(psa::SeqAcc), 256);
   const size_t o_fs = align_up(o_cnt + 64, 256);
   const size_t o_active = align_up(o_fs + (size_t)fs_total * sizeof(float), 256);
   const size_t dev_bytes = align_up(o_active + (size_t)fs_total * sizeof(psa::ActiveOffset), 256) + 256;
@@ -539,13 +550,13 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       u->pass_ev.push_back(e);
     }
     // stage the work lists in pinned memory and send them with one asynchronous copy on the
-    // copy stream (beside whatever runs are enqueued); the first run waits for its event
+    // pre-pass stream (beside whatever runs are enqueued); the first run waits for its event
     if (!pool.empty()) std::memcpy(u->pin + o_pool, pool.data(), pool.size());
     if (!b->desc.empty()) std::memcpy(u->pin + o_desc, b->desc.data(), b->desc.size() * sizeof(psa::SeqDesc));
     if (!fwd.empty()) std::memcpy(u->pin + o_fwd, fwd.data(), fwd.size() * sizeof(psa::FwdBlock));
     if (!chunks.empty()) std::memcpy(u->pin + o_chunks, chunks.data(), chunks.size() * sizeof(psa::Chunk));
-    PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_copy));
-    PSA_HIP_B(hipEventRecord(u->ev[5], c->st_copy));
+    PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_pre));
+    PSA_HIP_B(hipEventRecord(u->ev[5], c->st_pre));
     b->ev_upload = u->ev[5];
     b->upload_in_flight = true;
     b->d_pool = u->dev + o_pool;
@@ -565,6 +576,8 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     b->ev_init = u->ev[2];
     b->ev_res = u->ev[3];
     b->ev_res_first = u->ev[4];
+    b->ev_tail[0] = u->ev[6];
+    b->ev_tail[1] = u->ev[7];
     for (size_t k = 0; k < b->passes.size(); ++k)
       for (int i = 0; i < 2; ++i) {
         b->passes[k].ev_b[i] = u->pass_ev[4 * k + (size_t)i];
@@ -589,12 +602,11 @@ int psa_batch_create_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s
 
 int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
 
-// Enqueues one run on the streams of the context: the enumeration (pre-pass on st_pre,
-// candidate loop, locate and the enumeration half of the records on st_enum) and the resolve
-// chain with its half of the records on st_res, side by side.  No host synchronisation, and in
-// the steady state no stream waits for another except the candidate loop for its pre-pass:
-// the events that time the run ride on kernel dispatches, the host waits for both record
-// kernels, and the accumulators are left reset by their last readers.
+// Enqueues one run on the streams of the context: pre-passes on st_pre; candidate loops
+// alternating between the two st_enum, the last one followed on its stream by locate and the
+// enumeration half of the records; the resolve chain with its half of the records on st_res.
+// No host synchronisation.  The events that time the run ride on kernel dispatches, the host
+// waits for the record kernels, and the accumulators are left reset by their last readers.
 static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   psa_ctx *c = b->ctx;
   const bool resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
@@ -602,30 +614,48 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   // only a batch's first run, or one after a failed run, needs the set-up kernel
   const bool init = !b->acc_ready;
   if (init) {
-    if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_enum, b->ev_upload, 0));
-    PSA_HIP(psa::launch_init(b->d_acc, b->n, b->d_counters, 1, c->st_enum));
+    // on st_res, which never waits for a candidate loop
+    if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_upload, 0));
+    PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 1, c->st_res));
     PSA_HIP(psa::debug_sync("psa_init_acc"));
     if (b->nchunks > 0)
-      PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, (size_t)b->nchunks * sizeof(unsigned long long), c->st_enum));
-    PSA_HIP(hipEventRecord(b->ev_init, c->st_enum));
+      PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, 2 * (size_t)b->nchunks * sizeof(unsigned long long), c->st_res));
+    PSA_HIP(hipEventRecord(b->ev_init, c->st_res));
     PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
-    PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
+    for (hipStream_t st : c->st_enum) PSA_HIP(hipStreamWaitEvent(st, b->ev_init, 0));
+    b->tail_recorded[0] = b->tail_recorded[1] = false;
   }
   b->acc_ready = false;
   *timed = false;
-  hipEvent_t ev_first = b->ev_first;  // start of the first kernel on the enumeration side
+  if (enumerate) b->acc_par ^= 1;
+  const int par = b->acc_par;
+  psa::SeqAcc *const eacc = b->d_acc + (size_t)par * (size_t)b->n;
+  unsigned long long *const chunk_best = b->d_chunk_best + (size_t)par * (size_t)b->nchunks;
+  psa::FinalParams F{};
+  F.seq1 = c->d_seq1;
+  F.seq2_pool = b->d_pool;
+  F.desc = b->d_desc;
+  F.acc = b->d_acc;
+  F.eacc = eacc;
+  F.nactive = b->d_counters;
+  F.class_t = c->d_class_t;
+  F.out = b->d_out;
+  F.stages = stages;
   if (enumerate) {
     psa::EnumParams P{};
     P.seq1 = c->d_seq1;
     P.len1 = c->len1;
     P.seq2_pool = b->d_pool;
     P.desc = b->d_desc;
-    P.acc = b->d_acc;
+    P.acc = eacc;
     P.table_t = c->d_table_t;
     // A pre-pass may fill a slab as soon as the last candidate loop that read it has finished,
     // so it runs beside the candidate loop of the pass before it (on the other slab) and, for
-    // runs enqueued back to back, beside the tail (locate, records) of the run before.
+    // runs enqueued back to back, beside the candidate loop of the run before.
     const bool piped = b->passes.size() > 1;
+    hipEvent_t ev_first = b->ev_first;              // start of the run's first enumeration kernel
+    hipEvent_t last_loop[2] = {nullptr, nullptr};  // per candidate-loop stream
+    int es = 0;
     for (size_t k = 0; k < b->passes.size(); ++k) {
       psa_batch::SlabPass &sp = b->passes[k];
       // a one-pass batch alternates between the slabs from run to run, so that the pre-pass of a
@@ -642,48 +672,54 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
         const int c0 = sp.cls_c0[cls + 1], c1 = sp.cls_c0[cls];
         if (c1 <= c0) continue;
         P.chunks = b->d_chunks + c0;
-        P.chunk_best = b->d_chunk_best + c0;
+        P.chunk_best = chunk_best + c0;
         P.nchunks = c1 - c0;
         P.fg = c->d_slab[buf];
-        PSA_HIP(psa::launch_enum_prep(cls, P, c->enum_f32, c->st_pre, ev_first, cls == last_cls ? c->ev_prep[k & 1] : nullptr));
+        PSA_HIP(psa::launch_enum_prep(cls, P, c->enum_f32, c->st_pre, ev_first,
+                                      cls == last_cls ? c->ev_prep[k & 1] : nullptr));
         ev_first = nullptr;
       }
-      PSA_HIP(hipStreamWaitEvent(c->st_enum, c->ev_prep[k & 1], 0));
+      es = c->enum_streams > 1 ? (c->enum_flip ^= 1) : 0;
+      hipStream_t st_loop = c->st_enum[es];
+      // this run's copy of the accumulators was last used two runs ago, maybe on the other stream
+      if (b->tail_recorded[par] && !last_loop[es]) PSA_HIP(hipStreamWaitEvent(st_loop, b->ev_tail[par], 0));
+      PSA_HIP(hipStreamWaitEvent(st_loop, c->ev_prep[k & 1], 0));
       psa::WaveParams W = sp.wave;
       W.chunks = b->d_chunks + sp.c0;
-      W.chunk_best = b->d_chunk_best + sp.c0;
+      W.chunk_best = chunk_best + sp.c0;
       W.desc = b->d_desc;
-      W.acc = b->d_acc;
-      // while other kernels run beside this one, 41 KB of LDS per workgroup (untouched) keep it
-      // to three workgroups of 8 waves per CU
-      int lds = (resolve || piped) ? 41 * 1024 : 0;
+      W.acc = eacc;
+      // 41 KB of LDS per workgroup (untouched) keep the candidate loops, two of which may be in
+      // flight, to three workgroups of 8 waves per CU between them: the short kernels of the
+      // other streams always find wave slots, registers and LDS
+      int lds = 41 * 1024;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
-      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, lds, c->st_enum, sp.ev_b[buf], sp.ev_e[buf]));
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;
       c->slab_reader[buf] = sp.ev_e[buf];
       c->slab_reader_batch[buf] = b;
+      last_loop[es] = sp.ev_e[buf];
     }
+    // locate and the records follow the last candidate loop on its stream; the candidate loops
+    // of the next run start on the other stream, on the other copy of the accumulators
+    hipStream_t st_tail = c->st_enum[es];
+    if (last_loop[es ^ 1]) PSA_HIP(hipStreamWaitEvent(st_tail, last_loop[es ^ 1], 0));
     for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
       const int c0 = b->cls_c0[cls + 1], c1 = b->cls_c0[cls];
       if (c1 <= c0) continue;
       P.chunks = b->d_chunks + c0;
-      P.chunk_best = b->d_chunk_best + c0;
+      P.chunk_best = chunk_best + c0;
       P.nchunks = c1 - c0;
       P.fg = nullptr;
-      PSA_HIP(psa::launch_enum_locate(cls, P, std::min(c1 - c0, 4 * c->num_cus), c->st_enum));
+      PSA_HIP(psa::launch_enum_locate(cls, P, std::min(c1 - c0, 4 * c->num_cus), st_tail));
     }
+    F.which = resolve ? PSA_STAGE_ENUMERATE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
+    PSA_HIP(psa::launch_finalize(F, b->n, st_tail, nullptr, b->ev_last));
+    PSA_HIP(psa::debug_sync("psa_finalize"));
+    PSA_HIP(hipEventRecord(b->ev_tail[par], st_tail));
+    b->tail_recorded[par] = true;
     *timed = true;
   }
-  psa::FinalParams F{};
-  F.seq1 = c->d_seq1;
-  F.seq2_pool = b->d_pool;
-  F.desc = b->d_desc;
-  F.acc = b->d_acc;
-  F.nactive = b->d_counters;
-  F.class_t = c->d_class_t;
-  F.out = b->d_out;
-  F.stages = stages;
-  F.which = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   if (resolve) {
     psa::ResolveParams P{};
     P.seq1 = c->d_seq1;
@@ -699,13 +735,14 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.pchunks = (b->max_len2 + 255) / 256;
     int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
     PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res, b->ev_res_first));
-    // the float32 half of the records is filled on the resolve stream, beside the enumeration
-    F.which = PSA_STAGE_RESOLVE;
-    PSA_HIP(psa::launch_finalize(F, b->n, c->st_res, nullptr, b->ev_res));
-    F.which = PSA_STAGE_ENUMERATE;
   }
-  PSA_HIP(psa::launch_finalize(F, b->n, c->st_enum, ev_first, b->ev_last));
-  PSA_HIP(psa::debug_sync("psa_finalize"));
+  if (resolve || !enumerate) {
+    // the float32 half of the records is filled on the resolve stream, beside the enumeration;
+    // a run without enumeration fills (clears) the other half here too
+    F.which = enumerate ? PSA_STAGE_RESOLVE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
+    PSA_HIP(psa::launch_finalize(F, b->n, c->st_res, resolve ? nullptr : b->ev_res_first, b->ev_res));
+    PSA_HIP(psa::debug_sync("psa_finalize"));
+  }
   b->acc_ready = true;  // psa_finalize leaves the accumulators reset
   return PSA_OK;
 }
@@ -730,7 +767,8 @@ int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
   }
   b->pending = true;
   b->pending_timed = timed;
-  b->pending_resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
+  // which record kernels this run has: the enumeration side's, the resolve side's, or both
+  b->pending_resolve = ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) || !timed;
   return PSA_OK;
 }
 
@@ -744,8 +782,8 @@ int psa_batch_wait(psa_batch *b) {
   }
   psa_ctx *c = b->ctx;
   PSA_HIP(hipSetDevice(c->device));
-  // the two record kernels are the last of their streams
-  PSA_HIP(hipEventSynchronize(b->ev_last));
+  // the record kernels are the last of their streams
+  if (b->pending_timed) PSA_HIP(hipEventSynchronize(b->ev_last));
   if (b->pending_resolve) PSA_HIP(hipEventSynchronize(b->ev_res));
   b->upload_in_flight = false;
   b->enum_ms = 0.f;
@@ -758,8 +796,8 @@ int psa_batch_wait(psa_batch *b) {
     }
   }
   // first kernel start to last kernel end over both sides
-  for (hipEvent_t first : {b->ev_first, b->pending_resolve ? b->ev_res_first : nullptr})
-    for (hipEvent_t last : {b->ev_last, b->pending_resolve ? b->ev_res : nullptr}) {
+  for (hipEvent_t first : {b->pending_timed ? b->ev_first : nullptr, b->pending_resolve ? b->ev_res_first : nullptr})
+    for (hipEvent_t last : {b->pending_timed ? b->ev_last : nullptr, b->pending_resolve ? b->ev_res : nullptr}) {
       float ms = 0.f;
       if (first && last && hipEventElapsedTime(&ms, first, last) == hipSuccess) b->total_ms = std::max(b->total_ms, ms);
     }

@@ -59,7 +59,8 @@ struct FinalParams {
   const unsigned char *seq1;
   const unsigned char *seq2_pool;
   const SeqDesc *desc;
-  SeqAcc *acc;                   // read, then reset for the next run
+  SeqAcc *acc;                   // float32 (resolve) accumulators: read, then reset for the next run
+  SeqAcc *eacc;                  // enumeration accumulators of this run (one of two copies): likewise
   unsigned *nactive;             // reset with the resolve half
   const unsigned char *class_t;  // residue class [seq2 code][seq1 code], stride 32
   psa_result *out;               // pinned host memory, written directly

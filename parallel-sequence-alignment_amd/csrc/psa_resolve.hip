@@ -477,6 +477,7 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   const int i = blockIdx.x;
   const SeqDesc d = P.desc[i];
   const SeqAcc a = P.acc[i];
+  const SeqAcc ea = P.eacc[i];
   psa_result *r = P.out + i;
   const int tid = threadIdx.x;
   // Each half is the last reader of its accumulators in a run and leaves them reset for the
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
       if (i == 0) *P.nactive = 0u;
     }
     if (P.which & PSA_STAGE_ENUMERATE) {
-      w->enum_key = 0ull;
-      w->enum_loc = ~0ull;
+      P.eacc[i].enum_key = 0ull;
+      P.eacc[i].enum_loc = ~0ull;
     }
   }
   if (uni((int)(P.which & PSA_STAGE_RESOLVE))) {
@@ -518,16 +519,16 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
     }
   }
   if (uni((int)(P.which & PSA_STAGE_ENUMERATE))) {
-    const bool enum_ok = uni((P.stages & PSA_STAGE_ENUMERATE) && d.frac_bits >= 0 && a.enum_loc != ~0ull);
+    const bool enum_ok = uni((P.stages & PSA_STAGE_ENUMERATE) && d.frac_bits >= 0 && ea.enum_loc != ~0ull);
     if (enum_ok) {
-      const int p = (int)(0xffffffffu - (uint32_t)a.enum_key);
-      const int q = (int)(a.enum_loc >> 32), s = (int)(uint32_t)a.enum_loc;
+      const int p = (int)(0xffffffffu - (uint32_t)ea.enum_key);
+      const int q = (int)(ea.enum_loc >> 32), s = (int)(uint32_t)ea.enum_loc;
       count_classes(P, d, s, p, q, lds_counts, r->enum_counts);
       if (tid == 0) {
         r->enum_n = p + 1;
         r->enum_k = q + 1;
         r->enum_offset = s;
-        r->enum_score = (int)((uint32_t)(a.enum_key >> 32) ^ 0x80000000u);
+        r->enum_score = (int)((uint32_t)(ea.enum_key >> 32) ^ 0x80000000u);
       }
     } else if (tid == 0) {
       r->enum_n = r->enum_k = r->enum_offset = r->enum_score = 0;
