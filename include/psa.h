@@ -104,7 +104,8 @@ int psa_batch_wait(psa_batch *b);
 /* copies the n records of the last run */
 int psa_batch_results(const psa_batch *b, psa_result *out);
 /* device time of the last run in milliseconds, from HIP events on the launch streams:
- * the candidate-loop kernel(s) of the enumeration stage alone, and first kernel start to last kernel end */
+ * the time during which a candidate-loop kernel of the enumeration stage was executing (passes of a
+ * large batch overlap), and first kernel start to last kernel end */
 int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms);
 int psa_batch_size(const psa_batch *b);
 void psa_batch_destroy(psa_batch *b);

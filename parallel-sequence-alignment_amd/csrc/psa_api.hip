@@ -131,6 +131,7 @@ struct psa_batch {
   // alternate between the copies, so that the candidate loop of a run can start while locate
   // and the records of the run before are still reading theirs.
   int acc_par = 0;
+  bool cap_loops = true;  // the candidate loops leave room on every CU for the short kernels (small batches)
   hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset
   bool tail_recorded[2] = {false, false};
   float enum_ms = 0.f, total_ms = 0.f;
@@ -365,8 +366,16 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     row_units += (int64_t)(d.s_end - d.s_begin) * levels_of(d.len2);
   }
   // enough units to keep every wave slot busy many times over, each unit long enough
-  // (about 30 us: 72000 cycles at ~333 cycles per 64 x 64 candidates) to hide its start-up
-  const int64_t ns_cap = std::max<int64_t>(1, row_units / (16 * (int64_t)c->num_cus * 32));
+  // (about 30 us: 72000 cycles at ~333 cycles per 64 x 64 candidates) to hide its start-up;
+  // a batch too small for that still gets about two rounds of units over the wave slots (for
+  // Seq1 = 3000, 4 x Seq2 = 2000: two offsets per unit, 5 % faster than one or four)
+  const int64_t slots = (int64_t)c->num_cus * 32;
+  const int64_t ns_cap = std::max<int64_t>({1, row_units / (16 * slots), std::min<int64_t>(2, (row_units + slots) / (2 * slots))});
+  // A batch with many rounds of units per wave slot lets its candidate loops take every wave
+  // slot (8 waves per SIMD: 7 to 10 % faster than 6); the short kernels of the other streams then
+  // move in as workgroups retire, which delays them by a few unit times -- nothing against such
+  // a run.  A small batch keeps the cap: its resolve chain is as long as its candidate loop.
+  b->cap_loops = row_units < 16 * slots;
   int min_ns = psa::kEnumMaxNs;
   for (int i : order) {
     psa::SeqDesc &d = b->desc[(size_t)i];
@@ -692,7 +701,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // 41 KB of LDS per workgroup (untouched) keep the candidate loops, two of which may be in
       // flight, to three workgroups of 8 waves per CU between them: the short kernels of the
       // other streams always find wave slots, registers and LDS
-      int lds = 41 * 1024;
+      int lds = b->cap_loops ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
       PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;
@@ -789,10 +798,21 @@ int psa_batch_wait(psa_batch *b) {
   b->enum_ms = 0.f;
   b->total_ms = 0.f;
   if (b->pending_timed) {
+    // time during which at least one candidate loop of the run was executing: consecutive
+    // passes run on two streams and overlap, so their durations do not simply add up
+    std::vector<std::pair<float, float>> iv;
     for (psa_batch::SlabPass &sp : b->passes) {
-      float ms = 0.f;
-      PSA_HIP(hipEventElapsedTime(&ms, sp.ev_b[sp.last_buf], sp.ev_e[sp.last_buf]));
-      b->enum_ms += ms;
+      float t0 = 0.f, t1 = 0.f;
+      PSA_HIP(hipEventElapsedTime(&t0, b->ev_first, sp.ev_b[sp.last_buf]));
+      PSA_HIP(hipEventElapsedTime(&t1, b->ev_first, sp.ev_e[sp.last_buf]));
+      iv.emplace_back(t0, t1);
+    }
+    std::sort(iv.begin(), iv.end());
+    float hi = -1e30f;
+    for (const auto &x : iv) {
+      if (x.first > hi) b->enum_ms += x.second - x.first;
+      else if (x.second > hi) b->enum_ms += x.second - hi;
+      hi = std::max(hi, x.second);
     }
   }
   // first kernel start to last kernel end over both sides
