@@ -24,7 +24,7 @@ def ctx(psa):
     c.close()
 
 
-def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=True):
+def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=True, sum_bits=None):
     for i, (seq2, r) in enumerate(zip(seq2s, results)):
         assert r.status == 0, (i, r.status)
         o = oracle.fast(seq1, seq2, table)
@@ -37,7 +37,7 @@ def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=
         L2 = len(seq2)
         assert r.candidates == (len(seq1) - L2 + 3) * (L2 * (L2 - 1) // 2)
         if enum:
-            fr, itab, exact = oracle.fixed_table(table, L2)
+            fr, itab, exact = oracle.fixed_table(table, L2, oracle.SUM_BITS_F32 if sum_bits is None else sum_bits)
             assert r.enum_frac_bits == fr and r.enum_exact == exact
             if fr >= 0:
                 e = oracle.enum_best(seq1, seq2, itab)
@@ -135,6 +135,82 @@ def test_exact_regime_weights(psa, ctx, oracle):
         res = ctx.score_batch(seq2s)
         assert all(r.enum_exact == 2 for r in res)
         check_against_oracle(oracle, seq1, seq2s, table, res)
+
+
+def test_enum_float32_limit(psa, ctx, oracle):
+    """The enumeration adds and compares in float32, which is exact only while every value is an
+    integer of at most 24 bits: weights with many fraction bits and tables whose scaled entries
+    times the Seq2 length come close to 2^23, against the oracle's integer enumeration."""
+    rng = np.random.default_rng(77)
+    seq1, seq2s = synth_problem(6, 1500, [255, 700, 1023, 1400])
+    tables = [oracle.comp_matrix(np.array(w, dtype=np.float32))
+              for w in ([1000.1, 0.3, 0.7, 0.001], [123.456, 77.7, 3.3, 0.9], [4095, 4094.5, 1, 3], [4, 0.25, 4, 4])]
+    tables.append(rng.uniform(-1, 1, 676).astype(np.float32))
+    tables.append((rng.integers(-2047, 2048, 676) * 2.0 ** -3).astype(np.float32))
+    ctx.set_seq1(seq1)
+    near = 0
+    for table in tables:
+        ctx.set_table(table)
+        res = ctx.score_batch(seq2s)
+        for seq2 in seq2s:
+            fr, itab, _ = oracle.fixed_table(table, len(seq2))
+            bound = int(np.abs(itab).max()) * len(seq2)
+            assert fr >= 0 and bound <= 2 ** 23 - 1
+            near += bound >= 2 ** 22
+        check_against_oracle(oracle, seq1, seq2s, table, res)
+    assert near >= 8  # most cases sit within a factor of two of the limit
+
+
+def test_enum_int32_arithmetic(psa, oracle, monkeypatch):
+    """PSA_ENUM_I32=1: the enumeration in int32 with 30-bit values (6 more fraction bits)."""
+    seq1, seq2s = synth_problem(8, 1800, [63, 64, 65, 300, 1025, 1700])
+    monkeypatch.setenv("PSA_ENUM_I32", "1")
+    c = psa.Context(0)
+    monkeypatch.delenv("PSA_ENUM_I32")
+    c.set_seq1(seq1)
+    for w in ([2, 1.5, 1.1, 1.3], [2, 1.5, 1, 1.25]):
+        w = np.array(w, dtype=np.float32)
+        c.set_weights(w)
+        res = c.score_batch(seq2s)
+        assert res[-1].enum_frac_bits == oracle.fixed_table(oracle.comp_matrix(w), 1700, oracle.SUM_BITS_I32)[0]
+        check_against_oracle(oracle, seq1, seq2s, oracle.comp_matrix(w), res, sum_bits=oracle.SUM_BITS_I32)
+    c.close()
+
+
+def test_runs_back_to_back_alternate(psa, oracle, monkeypatch):
+    """Seven runs of one resident batch enqueued at once (consecutive candidate loops alternate
+    between two streams, two slabs and two copies of the accumulators and overlap), for a one-pass
+    and a many-pass batch, and the same with a single candidate-loop stream."""
+    seq1, seq2s = synth_problem(12, 2500, [1999, 700, 1200, 64, 2000])
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    want = None
+    for slab_mb, streams in ((None, None), ("5", None), (None, "1"), ("5", "1")):
+        if slab_mb:
+            monkeypatch.setenv("PSA_SLAB_MB", slab_mb)
+        if streams:
+            monkeypatch.setenv("PSA_ENUM_STREAMS", streams)
+        c = psa.Context(0)
+        c.set_seq1(seq1)
+        c.set_weights(w)
+        b = c.batch(seq2s)
+        monkeypatch.delenv("PSA_SLAB_MB", raising=False)
+        monkeypatch.delenv("PSA_ENUM_STREAMS", raising=False)
+        for _ in range(7):
+            b.enqueue()
+        b.wait()
+        got = [r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in b.results()]
+        if want is None:
+            check_against_oracle(oracle, seq1, seq2s, oracle.comp_matrix(w), b.results())
+            want = got
+        assert got == want
+        b.enqueue(psa.STAGE_ENUMERATE)
+        b.enqueue()
+        b.enqueue(psa.STAGE_RESOLVE)
+        b.enqueue()
+        b.wait()
+        assert [r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in b.results()] == want
+        b.close()
+        c.close()
 
 
 def test_edge_stress(psa, ctx, oracle):
