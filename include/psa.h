@@ -48,7 +48,10 @@ typedef enum psa_status {
  * (identical, conservative, semi-conservative, other) of that winner.
  * The enum_* fields describe the enumeration stage: every candidate is scored
  * as the exact integer sum of table entries scaled by 2^enum_frac_bits and
- * rounded to nearest; enum_exact is 2 when that equals the float32 arithmetic
+ * rounded to nearest (the scale is the largest that keeps every such sum within
+ * 24 bits, so that the kernels can add them exactly in float32; 30 bits and
+ * int32 arithmetic with PSA_ENUM_I32=1 in the environment of psa_init);
+ * enum_exact is 2 when that equals the float32 arithmetic
  * of the reference for every candidate (then both winners coincide), 1 when
  * only the table is represented exactly, 0 otherwise, -1 if the stage did not
  * run. */
@@ -61,7 +64,7 @@ typedef struct psa_result {
   int32_t counts[4];
   int32_t enum_n, enum_k, enum_offset;
   int32_t enum_score;     /* fixed point, units of 2^-enum_frac_bits */
-  int32_t enum_frac_bits; /* -1: table too large for int32 fixed point */
+  int32_t enum_frac_bits; /* -1: table too large for the fixed-point range */
   int32_t enum_exact;
   int32_t enum_counts[4];
   int32_t status;         /* psa_status of this Seq2 */

@@ -10,7 +10,7 @@
 // entries along diagonal delta,
 //   score = f_s[p] + g_s[q],  f_s[p] = E^s[p] - E^{s-1}[p+1],
 //                             g_s[q] = E^{s-1}[q] + E^{s-2}[L2] - E^{s-2}[q+1],
-// so every (s,p,q) costs one integer add and one max.
+// so every (s,p,q) costs one add and one max.
 //
 // Three kernels:
 //   psa_enum_prep    one workgroup per chunk of offsets: prefix sums of the diagonals in
@@ -23,9 +23,12 @@
 //   psa_enum_locate  second pass over the few chunks that hold the maximum: smallest q
 //                    and offset for the winning p.
 //
-// Instruction mix (measured on MI355X): v_add_u32 issues at full rate, every integer
-// or float min/max at half rate, so two candidates are folded into one v_max3_i32:
-// 2 adds + 1 max3 per two candidates.
+// Instruction mix (measured on MI355X): adds issue at full rate, every integer or float
+// min/max at half rate, so two candidates are folded into one max3: 2 adds + 1 max3 per
+// two candidates.  The float32 pair (v_add_f32, v_max3_f32) issues about a fifth faster
+// than the int32 pair, and float32 adds integers of at most 24 bits exactly, so the
+// default scale keeps f, g and f + g within 24 bits and the loop runs in float32; the
+// int32 form of the same kernels (30-bit values) is kept behind a switch.
 #include <hip/hip_ext.h>
 
 #include "psa_device.h"

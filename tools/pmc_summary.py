@@ -13,7 +13,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {
-    "command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "
+    "command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --no-cpu-baseline --sync-steps --steps 3 --warmup 1 "
                "(one pass each: FETCH_SIZE; WRITE_SIZE; GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU "
                "SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES)",
     "units": "mean per dispatch; FETCH_SIZE and WRITE_SIZE in KB as rocprofv3 reports them (on gfx950 FETCH_SIZE "
