@@ -237,7 +237,8 @@ def main():
         cand_total = float(cand_rank)
 
     if rank == 0:
-        enum_dtype = "i32" if os.environ.get("PSA_ENUM_I32", "0") not in ("", "0") else "f32 (24-bit integers)"
+        # float32 throughout by default (the enumeration on integer-valued float32, the resolve on the reference's sums)
+        enum_dtype = "i32+f32" if os.environ.get("PSA_ENUM_I32", "0") not in ("", "0") else "f32"
         value = cand_total * args.steps / elapsed
         out = {
             "metric": "scored (offset,mutant) candidates/sec",
@@ -247,7 +248,7 @@ def main():
             "gpu_ms_per_step_alone": (iso_gpu_ms / n_iso) if n_iso else gpu_ms / args.steps,
             "higher_is_better": True,
             "scaling": "strong" if args.config == "c4" else "weak",
-            "vs_baseline": None, "dtype": enum_dtype + " (enumeration) + f32 (exact resolve)", "data": "synthetic"
+            "vs_baseline": None, "dtype": enum_dtype, "data": "synthetic"
             if args.config != "c1" else "reference sample input",
             "config": {"workload": name, "stages": args.stages, "weights": [float(x) for x in WEIGHTS],
                        "candidates_per_step": cand_total, "seed": "2 + 1000*rank"},
