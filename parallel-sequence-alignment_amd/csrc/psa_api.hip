@@ -482,7 +482,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       c->slab_units = 0;
       c->slab_count = 0;
       for (int i = 0; i < count; ++i) {
-        // one extra run: the candidate loop's look-ahead reads 16 values past the last row
+        // one extra run: the candidate loop's per-lane load of g[p + 1] reads one value past the last row
         if (hipMalloc((void **)&c->d_slab[i], (units + 1) * kSlabUnit) != hipSuccess) {
           g_err = "hipMalloc(enumeration slab) failed";
           return fail(PSA_ERR_HIP);

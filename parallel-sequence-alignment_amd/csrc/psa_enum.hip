@@ -17,9 +17,9 @@
 //                    LDS, then one row of f and one row of g per offset into a slab in HBM
 //                    (8 bytes per position and offset, against L2/2 candidates each);
 //   psa_enum_wave    the candidate loop.  One wave per (offsets, 256 positions p): f sits
-//                    in 4 vector registers per lane, g arrives through scalar loads and is
-//                    used straight from scalar registers; no LDS, no barriers, so waves
-//                    are scheduled one by one and the chip stays full to the last unit;
+//                    in 4 vector registers per lane, g arrives through scalar loads (it is
+//                    wave-uniform); no LDS, no barriers, so waves are scheduled one by
+//                    one and the chip stays full to the last unit;
 //   psa_enum_locate  second pass over the few chunks that hold the maximum: smallest q
 //                    and offset for the winning p.
 //
