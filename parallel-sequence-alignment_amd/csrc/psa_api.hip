@@ -132,8 +132,9 @@ struct psa_batch {
   // and the records of the run before are still reading theirs.
   int acc_par = 0;
   bool cap_loops = true;  // the candidate loops leave room on every CU for the short kernels (small batches)
-  hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset
+  hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset: end of that run's record kernel
   bool tail_recorded[2] = {false, false};
+  int tail_stream[2] = {0, 0};                 // the candidate-loop stream that event is on
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
@@ -691,7 +692,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       es = c->enum_streams > 1 ? (c->enum_flip ^= 1) : 0;
       hipStream_t st_loop = c->st_enum[es];
       // this run's copy of the accumulators was last used two runs ago, maybe on the other stream
-      if (b->tail_recorded[par] && !last_loop[es]) PSA_HIP(hipStreamWaitEvent(st_loop, b->ev_tail[par], 0));
+      if (b->tail_recorded[par] && !last_loop[es] && b->tail_stream[par] != es)
+        PSA_HIP(hipStreamWaitEvent(st_loop, b->ev_tail[par], 0));
       PSA_HIP(hipStreamWaitEvent(st_loop, c->ev_prep[k & 1], 0));
       psa::WaveParams W = sp.wave;
       W.chunks = b->d_chunks + sp.c0;
@@ -723,10 +725,11 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       PSA_HIP(psa::launch_enum_locate(cls, P, std::min(c1 - c0, 4 * c->num_cus), st_tail));
     }
     F.which = resolve ? PSA_STAGE_ENUMERATE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
+    b->ev_last = b->ev_tail[par];
     PSA_HIP(psa::launch_finalize(F, b->n, st_tail, nullptr, b->ev_last));
     PSA_HIP(psa::debug_sync("psa_finalize"));
-    PSA_HIP(hipEventRecord(b->ev_tail[par], st_tail));
     b->tail_recorded[par] = true;
+    b->tail_stream[par] = es;
     *timed = true;
   }
   if (resolve) {

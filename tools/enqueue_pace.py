@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Host time of each psa_batch_enqueue call on the default bench workload (is the host ahead of
-the GPU when runs are enqueued back to back?).  Usage: python3 tools/enqueue_pace.py [steps]"""
+the GPU when runs are enqueued back to back?).  Usage: python3 tools/enqueue_pace.py [steps [c1 | c2]]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "parallel-sequence-alignment_amd"))
 import bench, psa_amd
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-_, seq1, seq2s, _ = bench.make_workload("c2", 0, 1, 0)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+_, seq1, seq2s, _ = bench.make_workload(cfg, 0, 1, 0)
 ctx = psa_amd.Context(0)
 ctx.set_seq1(seq1)
 ctx.set_weights(bench.WEIGHTS)
