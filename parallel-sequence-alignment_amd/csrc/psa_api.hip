@@ -135,6 +135,8 @@ struct psa_batch {
   hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset: end of that run's record kernel
   bool tail_recorded[2] = {false, false};
   int tail_stream[2] = {0, 0};                 // the candidate-loop stream that event is on
+  bool last_run_res_only = false;  // the run before wrote both halves of the records on st_res
+  bool res_recorded = false;       // ev_res has been recorded (some run had a record kernel on st_res)
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
@@ -715,6 +717,11 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     // of the next run start on the other stream, on the other copy of the accumulators
     hipStream_t st_tail = c->st_enum[es];
     if (last_loop[es ^ 1]) PSA_HIP(hipStreamWaitEvent(st_tail, last_loop[es ^ 1], 0));
+    // runs of one batch write one set of records: this run's must land after those of a run
+    // without enumeration enqueued just before it; and a run without the resolve stage, whose
+    // record kernel also resets the resolve accumulators, after the resolve chain before it
+    if (b->last_run_res_only || (!resolve && b->res_recorded)) PSA_HIP(hipStreamWaitEvent(st_tail, b->ev_res, 0));
+    b->last_run_res_only = false;
     for (int cls = psa::kEnumClasses - 1; cls >= 0; --cls) {
       const int c0 = b->cls_c0[cls + 1], c1 = b->cls_c0[cls];
       if (c1 <= c0) continue;
@@ -752,7 +759,14 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     // the float32 half of the records is filled on the resolve stream, beside the enumeration;
     // a run without enumeration fills (clears) the other half here too
     F.which = enumerate ? PSA_STAGE_RESOLVE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
+    if (!enumerate) {
+      // ... and after those of enumerating runs still in flight, whose accumulators it also resets
+      for (int i = 0; i < 2; ++i)
+        if (b->tail_recorded[i]) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_tail[i], 0));
+      b->last_run_res_only = true;
+    }
     PSA_HIP(psa::launch_finalize(F, b->n, c->st_res, resolve ? nullptr : b->ev_res_first, b->ev_res));
+    b->res_recorded = true;
     PSA_HIP(psa::debug_sync("psa_finalize"));
   }
   b->acc_ready = true;  // psa_finalize leaves the accumulators reset

@@ -209,6 +209,17 @@ def test_runs_back_to_back_alternate(psa, oracle, monkeypatch):
         b.enqueue()
         b.wait()
         assert [r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in b.results()] == want
+        # mixed stages back to back: the records are those of the last run enqueued
+        b.enqueue()
+        b.enqueue(psa.STAGE_RESOLVE)
+        b.wait()
+        assert [r.key() + tuple(r.counts) for r in b.results()] == [w[:4] + w[8:12] for w in want]
+        assert all(r.enum_n == 0 and r.enum_score == 0 for r in b.results())
+        b.enqueue(psa.STAGE_RESOLVE)
+        b.enqueue(psa.STAGE_ENUMERATE)
+        b.wait()
+        assert [r.enum_key() + tuple(r.enum_counts) for r in b.results()] == [w[4:8] + w[12:16] for w in want]
+        assert all(r.n == 0 and r.score_bits == 0 for r in b.results())
         b.close()
         c.close()
 
