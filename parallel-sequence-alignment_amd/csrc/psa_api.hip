@@ -729,7 +729,10 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       P.chunk_best = chunk_best + c0;
       P.nchunks = c1 - c0;
       P.fg = nullptr;
-      PSA_HIP(psa::launch_enum_locate(cls, P, std::min(c1 - c0, 4 * c->num_cus), st_tail));
+      // few workgroups, each walking many chunks: nearly every chunk is skipped after two loads,
+      // and a workgroup that reserves its LDS beside the candidate loops is slow to place
+      const int grid = std::min({c1 - c0, std::max(64, (c1 - c0) / 16), 4 * c->num_cus});
+      PSA_HIP(psa::launch_enum_locate(cls, P, grid, st_tail));
     }
     F.which = resolve ? PSA_STAGE_ENUMERATE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
     b->ev_last = b->ev_tail[par];
