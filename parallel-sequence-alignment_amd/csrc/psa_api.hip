@@ -137,6 +137,7 @@ struct psa_batch {
   int tail_stream[2] = {0, 0};                 // the candidate-loop stream that event is on
   bool last_run_res_only = false;  // the run before wrote both halves of the records on st_res
   bool res_recorded = false;       // ev_res has been recorded (some run had a record kernel on st_res)
+  hipEvent_t enum_only_tail = nullptr;  // record kernel of a run without the resolve stage, not yet ordered before st_res
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
@@ -742,6 +743,12 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     b->tail_stream[par] = es;
     *timed = true;
   }
+  if ((resolve || !enumerate) && b->enum_only_tail) {
+    // the record kernel of a run without the resolve stage (the run before this one) clears the
+    // float32 half of the records and resets the resolve accumulators: this chain starts after it
+    PSA_HIP(hipStreamWaitEvent(c->st_res, b->enum_only_tail, 0));
+  }
+  b->enum_only_tail = (enumerate && !resolve) ? b->ev_last : nullptr;
   if (resolve) {
     psa::ResolveParams P{};
     P.seq1 = c->d_seq1;

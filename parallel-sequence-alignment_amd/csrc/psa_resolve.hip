@@ -485,13 +485,15 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   __syncthreads();
   if (tid == 0) {
     SeqAcc *w = P.acc + i;
-    if (P.which & PSA_STAGE_RESOLVE) {
+    // (only what this run's stages used: a run without a stage clears that half of the records
+    // but must not touch accumulators that a run enqueued behind it may already be filling)
+    if (P.which & P.stages & PSA_STAGE_RESOLVE) {
       w->res_loc = ~0ull;
       w->res_key = 0u;
       w->res_p = INT_MAX;
       if (i == 0) *P.nactive = 0u;
     }
-    if (P.which & PSA_STAGE_ENUMERATE) {
+    if (P.which & P.stages & PSA_STAGE_ENUMERATE) {
       P.eacc[i].enum_key = 0ull;
       P.eacc[i].enum_loc = ~0ull;
     }
