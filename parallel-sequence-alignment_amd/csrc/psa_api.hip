@@ -708,7 +708,11 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // other streams always find wave slots, registers and LDS
       int lds = b->cap_loops ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
-      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
+      // capped launches keep workgroups of 8 waves (the cap counts workgroups); the others use
+      // workgroups of one wave, which take a wave slot as soon as one is free
+      int wpg = b->cap_loops ? 8 : 1;
+      if (const char *e = std::getenv("PSA_ENUM_WPG")) wpg = std::max(1, std::min(8, std::atoi(e)));  // tuning aid
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;
       c->slab_reader[buf] = sp.ev_e[buf];
       c->slab_reader_batch[buf] = b;

@@ -421,18 +421,22 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
   }
 }
 
-// A workgroup is 8 independent waves, each scoring one unit: no barrier, no LDS traffic.
+// A workgroup is 1 to 8 independent waves, each scoring one unit: no barrier, no LDS traffic.
 // Workgroups are launched in unit order and the SIMD issues its oldest wave first, so units
 // finish roughly in the order they were numbered (largest first) and the last waves of a
 // launch are short ones.  (Resident waves that draw unit numbers from a counter were
 // measured 25 % slower: the issue order starves the youngest waves of each SIMD, which
 // then hold their first, largest units until every other wave has run out of work.)
-// The launch may ask for LDS it never uses: 41 KB pins three workgroups per CU, which
-// leaves wave slots, registers and LDS for the short kernels of the other streams.
+// The launch may ask for LDS it never uses: 41 KB pins three workgroups of 8 waves per CU,
+// which leaves wave slots, registers and LDS for the short kernels of the other streams.
+// A launch that takes every wave slot uses workgroups of one wave: a workgroup is placed only
+// when all its waves find slots on one CU, so with 8-wave workgroups the slots of finished
+// waves idle until 8 are free (units of mixed lengths: 64.8 against 55.4 ms on 256 Seq2 of
+// 500 to 2000 characters).
 template <int R, bool F32>
 __global__ __launch_bounds__(512, 8) void psa_enum_wave(const int *__restrict__ fg, WaveParams P) {
   const int lane = threadIdx.x & 63;
-  const int u = uni((int)(blockIdx.x * 8 + (threadIdx.x >> 6)));
+  const int u = uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (u < P.nunits) wave_unit<R, F32>(fg, P, u, lane);
 }
 
@@ -540,14 +544,16 @@ static hipError_t launch_locate_t(const EnumParams &P, int grid, hipStream_t st)
   return debug_sync("psa_enum_locate");
 }
 
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int lds_bytes, hipStream_t st,
-                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int waves_per_group, int lds_bytes,
+                            hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (waves_per_group < 1 || waves_per_group > 8) return hipErrorInvalidValue;
+  const dim3 grid((P.nunits + waves_per_group - 1) / waves_per_group), block(64 * waves_per_group);
   // the events ride on the kernel's own dispatch packet: no marker packets before or after it
   if (f32)
-    hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, true>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st,
+    hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, true>), grid, block, lds_bytes, st,
                           ev_start, ev_stop, 0, fg, P);
   else
-    hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, false>), dim3((P.nunits + 7) / 8), dim3(512), lds_bytes, st,
+    hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, false>), grid, block, lds_bytes, st,
                           ev_start, ev_stop, 0, fg, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

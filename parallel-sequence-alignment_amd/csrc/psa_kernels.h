@@ -80,8 +80,9 @@ hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hi
 // (exact: the scale keeps every value an integer of at most 24 bits); otherwise int32
 hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
                             hipEvent_t ev_stop);
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int lds_bytes, hipStream_t st,
-                            hipEvent_t ev_start, hipEvent_t ev_stop);
+// (workgroups of waves_per_group waves, 1 to 8, one unit per wave; lds_bytes are requested per workgroup and never touched)
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int waves_per_group, int lds_bytes,
+                            hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st);
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,
                           hipEvent_t ev_start);

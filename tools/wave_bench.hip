@@ -2,7 +2,7 @@
 // rest of a run around it.
 // Build: hipcc -O3 --offload-arch=gfx950 -I../include -o wave_bench wave_bench.hip \
 //        -L../parallel-sequence-alignment_amd -lpsa_hip -Wl,-rpath,'$ORIGIN/../parallel-sequence-alignment_amd'
-// Run:   ./wave_bench [offsets] [len2] [enum_ns] [sub_log2] [reps] [lds_bytes] [f32: 1 (default) or 0]
+// Run:   ./wave_bench [offsets] [len2] [enum_ns] [sub_log2] [reps] [lds_bytes] [f32: 1 (default) or 0] [waves per workgroup, default 8]
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
@@ -30,6 +30,7 @@ int main(int argc, char **argv) {
   const int reps = argc > 5 ? std::atoi(argv[5]) : 20;
   const int lds = argc > 6 ? std::atoi(argv[6]) : 0;
   const bool f32 = argc > 7 ? std::atoi(argv[7]) != 0 : true;
+  const int wpg = argc > 8 ? std::atoi(argv[8]) : 8;
   const int nruns = (len2 + 63) / 64, stride = 128 * nruns + 64;
   const int levels = (nruns + psa::kEnumWaveRuns - 1) / psa::kEnumWaveRuns;
   const int per = std::min(ens << sub_log2, psa::kEnumMaxNs);
@@ -92,10 +93,10 @@ int main(int argc, char **argv) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  CK(psa::launch_enum_wave(dfg, W, f32, lds, st, nullptr, nullptr));
+  CK(psa::launch_enum_wave(dfg, W, f32, wpg, lds, st, nullptr, nullptr));
   CK(hipStreamSynchronize(st));
   CK(hipEventRecord(a, st));
-  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, f32, lds, st, nullptr, nullptr));
+  for (int i = 0; i < reps; ++i) CK(psa::launch_enum_wave(dfg, W, f32, wpg, lds, st, nullptr, nullptr));
   CK(hipEventRecord(b, st));
   CK(hipEventSynchronize(b));
   float ms = 0;
