@@ -374,10 +374,19 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
   const int qlast = (L2 + 15) & ~15;     // the candidate loop stops at the 16-value step that holds q = L2 - 1
   const int pc0 = w * R;
   const int *__restrict__ F = fg + ((size_t)ch.fg_row + (size_t)r0 * (2 * nruns + 1)) * 64;
+  // Register r holds run pc0 + r of p; past the last run it repeats that run (its maxima are
+  // dropped below).  The per-lane loads are buffer loads: the unit's first row is the base, a
+  // scalar byte offset walks the rows, and one register per run holds the lane's byte offset
+  // within a row -- no 64-bit address arithmetic in vector registers.
+  const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc((void *)F, 0, -1, 0x00020000);
+  int vb[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) vb[r] = 4 * (64 * min(pc0 + r, nruns - 1) + lane);
+  int soff = 0;  // byte offset of the current row (at most kEnumMaxNs rows of 2 * 128 + 1 runs)
   int fn[R], acc[R][2];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
+    fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff, 0);
     acc[r][0] = acc[r][1] = Cand<F32>::lowest;
   }
   for (int i = r0; i < r1; ++i) {
@@ -385,14 +394,16 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
     for (int r = 0; r < R; ++r) f[r] = fn[r];
     const int *__restrict__ G = F + qend;
+    const int goff = soff + 4 * qend + 4;  // g[p + 1] per lane: the diagonal's left-over pairs
     F += 2 * qend + 64;
+    soff += 4 * (2 * qend + 64);
     if (i + 1 < r1) {  // next offset's f values arrive while this one is scored
 #pragma unroll
-      for (int r = 0; r < R; ++r) fn[r] = pc0 + r < nruns ? F[64 * (pc0 + r) + lane] : 0;
+      for (int r = 0; r < R; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff, 0);
     }
-    int gnext[R];  // g[p + 1] per lane: the diagonal's left-over pairs
+    int gnext[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) gnext[r] = G[(pc0 + r < nruns ? 64 * (pc0 + r) : 0) + lane + 1];
+    for (int r = 0; r < R; ++r) gnext[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], goff, 0);
     wave_full<R, F32>(G, 64 * (pc0 + R), qlast, f, acc);
     WaveOwn<R, R - 1, F32>::run(G, pc0, nruns, f, acc);
     if ((lane & 1) == 0) {
