@@ -168,9 +168,19 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP(hipSetDevice(device));
   psa_ctx *c = new (std::nothrow) psa_ctx();
   if (!c) return PSA_ERR_NOMEM;
+  // (a failure below releases what the context already holds)
+#define PSA_HIP_C(call)                                          \
+  do {                                                           \
+    hipError_t e_ = (call);                                      \
+    if (e_ != hipSuccess) {                                      \
+      g_err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      psa_shutdown(c);                                           \
+      return PSA_ERR_HIP;                                        \
+    }                                                            \
+  } while (0)
   c->device = device;
   hipDeviceProp_t prop;
-  PSA_HIP(hipGetDeviceProperties(&prop, device));
+  PSA_HIP_C(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PSA_ENUM_I32")) c->enum_f32 = std::atoi(e) == 0;
   // Every stream has the same priority.  (With the short kernels' streams at a higher priority
@@ -179,17 +189,18 @@ int psa_init(int device, psa_ctx **out) {
   // cap themselves at three workgroups per CU (see enqueue_run), not through priority.  Four
   // streams, because a process has four hardware queues here: a fifth stream shares a queue
   // with another one and runs in order with it.
-  for (hipStream_t &st : c->st_enum) PSA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  PSA_HIP(hipStreamCreateWithFlags(&c->st_res, hipStreamNonBlocking));
-  PSA_HIP(hipStreamCreateWithFlags(&c->st_pre, hipStreamNonBlocking));
+  for (hipStream_t &st : c->st_enum) PSA_HIP_C(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  PSA_HIP_C(hipStreamCreateWithFlags(&c->st_res, hipStreamNonBlocking));
+  PSA_HIP_C(hipStreamCreateWithFlags(&c->st_pre, hipStreamNonBlocking));
   if (const char *e = std::getenv("PSA_ENUM_STREAMS")) c->enum_streams = std::atoi(e) == 1 ? 1 : 2;  // tuning aid
-  for (hipEvent_t &e : c->ev_prep) PSA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  PSA_HIP(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
-  PSA_HIP(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
+  for (hipEvent_t &e : c->ev_prep) PSA_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  PSA_HIP_C(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
+  PSA_HIP_C(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
   std::vector<unsigned char> cls(psa::kDevTable, 3);
   for (int b = 0; b < 26; ++b)
     for (int a = 0; a < 26; ++a) cls[b * psa::kRowStride + a] = (unsigned char)psa::residue_class_code(a, b);
-  PSA_HIP(hipMemcpy(c->d_class_t, cls.data(), cls.size(), hipMemcpyHostToDevice));
+  PSA_HIP_C(hipMemcpy(c->d_class_t, cls.data(), cls.size(), hipMemcpyHostToDevice));
+#undef PSA_HIP_C
   *out = c;
   return PSA_OK;
 }

@@ -14,6 +14,7 @@ echo benches c2 c1 done
 timeout -k 10 300 python3 bench.py --config c2 --sync-steps --no-cpu-baseline > $out/${tag}_bench_c2_sync_steps.json 2>> $out/bench_c2.err || exit 1
 timeout -k 10 300 python3 bench.py --config c3 --steps 3 --warmup 1 > $out/${tag}_bench_c3_256seq.json 2> $out/bench_c3.err || exit 1
 timeout -k 10 300 python3 bench.py --config c4 --steps 3 --warmup 1 > $out/${tag}_bench_c4_1gpu.json 2> $out/bench_c4.err || exit 1
+timeout -k 10 300 python3 bench.py --config c3 --nseq2 4096 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_4096seq.json 2>> $out/bench_c3.err || exit 1
 echo benches done
 # kernel statistics: the default command (consecutive candidate loops share the GPU inside its
 # timed region) and the same with --sync-steps (every launch on its own: the duration the
