@@ -315,38 +315,45 @@ __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int
 // q0 + i + 1, is the pair (p, p + 1) of every even lane and is added by the caller from a
 // per-lane load.  The sums are formed in every lane; only the max3 runs under the lane
 // mask, which is written to exec and restored inside one asm statement (the wave is
-// whole here: a unit is wave-uniform work).
+// whole here: a unit is wave-uniform work).  One call takes steps I .. I + 3 (g[0..3]).
 template <int I, bool F32>
-__device__ __forceinline__ void diag_steps(const int *g, int f, int (&acc)[2]) {
-  if constexpr (I < 64) {
-    const int t0 = Cand<F32>::add_sv(g[I], f), t1 = Cand<F32>::add_sv(g[I + 1], f);
-    if constexpr (I + 2 < 64) {
-      const int t2 = Cand<F32>::add_sv(g[I + 2], f), t3 = Cand<F32>::add_sv(g[I + 3], f);
-      Cand<F32>::template max3_masked2<I, I + 2>(acc[0], t0, t1, acc[1], t2, t3);
-    } else {
-      Cand<F32>::template max3_masked1<I>(acc[0], t0, t1);
-    }
-    diag_steps<I + 4, F32>(g, f, acc);
+__device__ __forceinline__ void diag_group(const int *g, int f, int (&acc)[2]) {
+  if constexpr (I == 0) {  // steps 0 and 1 pair with no lane
+    const int t2 = Cand<F32>::add_sv(g[2], f), t3 = Cand<F32>::add_sv(g[3], f);
+    Cand<F32>::template max3_masked1<2>(acc[1], t2, t3);
+  } else {
+    const int t0 = Cand<F32>::add_sv(g[0], f), t1 = Cand<F32>::add_sv(g[1], f);
+    const int t2 = Cand<F32>::add_sv(g[2], f), t3 = Cand<F32>::add_sv(g[3], f);
+    Cand<F32>::template max3_masked2<I, I + 2>(acc[0], t0, t1, acc[1], t2, t3);
   }
 }
 
 // The q runs of the level's own R runs of p: run pc0 + J pairs with every lane of
-// registers 0..J-1 and with register J along the diagonal.  Its 64 values of g are
-// fetched with one group of scalar loads and stay in scalar registers for all of that.
+// registers 0..J-1 and with register J along the diagonal, 16 values of g at a time (one
+// scalar load each, as in the long phase: holding all 64 values of a run in scalar registers
+// left too few for the loop's own scalars, which hipcc then parked in vector-register lanes).
+template <int R, int J, int C, bool F32>
+__device__ __forceinline__ void own_chunk(const int *__restrict__ Gj, const int (&f)[R], int (&acc)[R][2]) {
+  int g[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) g[i] = Gj[16 * C + i];
+  if constexpr (J > 0) wave_step16<R, J, F32>(g, f, acc);
+  diag_group<16 * C, F32>(g, f[J], acc[J]);
+  diag_group<16 * C + 4, F32>(g + 4, f[J], acc[J]);
+  diag_group<16 * C + 8, F32>(g + 8, f[J], acc[J]);
+  diag_group<16 * C + 12, F32>(g + 12, f[J], acc[J]);
+}
 template <int R, int J, bool F32>
 struct WaveOwn {
   __device__ static __forceinline__ void run(const int *__restrict__ G, int pc0, int nruns, const int (&f)[R],
                                              int (&acc)[R][2]) {
     WaveOwn<R, J - 1, F32>::run(G, pc0, nruns, f, acc);
     if (pc0 + J < nruns) {
-      int g[64];
-#pragma unroll
-      for (int i = 0; i < 64; ++i) g[i] = G[64 * (pc0 + J) + i];
-      if constexpr (J > 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) wave_step16<R, J, F32>(g + 16 * c, f, acc);
-      }
-      diag_steps<2, F32>(g, f[J], acc[J]);
+      const int *__restrict__ Gj = G + 64 * (pc0 + J);
+      own_chunk<R, J, 0, F32>(Gj, f, acc);
+      own_chunk<R, J, 1, F32>(Gj, f, acc);
+      own_chunk<R, J, 2, F32>(Gj, f, acc);
+      own_chunk<R, J, 3, F32>(Gj, f, acc);
     }
   }
 };
