@@ -446,21 +446,34 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
 // ---------------------------------------------------------------------------------
 // result records: decode the accumulators and count residue classes of the winners
 // ---------------------------------------------------------------------------------
-__device__ void count_classes(const FinalParams &P, const SeqDesc &d, int s, int p, int q, int *lds_counts,
-                              int32_t *out) {
+// (the class table sits in LDS; a thread fetches the residues of up to 8 positions before it
+// looks any of them up, so the global-memory latency is paid once, not once per position)
+__device__ void count_classes(const FinalParams &P, const SeqDesc &d, int s, int p, int q,
+                              const unsigned char *lds_class, int *lds_counts, int32_t *out) {
   const int tid = threadIdx.x;
   if (tid < 4) lds_counts[tid] = 0;
   __syncthreads();
   int local[4] = {0, 0, 0, 0};
   const int m = d.len2 - 2;
-  for (int i = tid; i < m; i += blockDim.x) {
-    const int j = i < p ? i : (i < q - 1 ? i + 1 : i + 2);
-    const int a = P.seq1[(int64_t)s + i], b = P.seq2_pool[d.off2 + j];
-    const int cls = P.class_t[b * kRowStride + a];
-    local[0] += cls == 0;
-    local[1] += cls == 1;
-    local[2] += cls == 2;
-    local[3] += cls == 3;
+  constexpr int U = 8;
+  const unsigned char *s1 = P.seq1 + (int64_t)s, *s2 = P.seq2_pool + d.off2;
+  for (int i0 = tid; i0 < m; i0 += U * 256) {
+    int a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u * 256, m - 1);
+      const int j = i < p ? i : (i < q - 1 ? i + 1 : i + 2);
+      a[u] = s1[i];
+      b[u] = s2[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cls = i0 + u * 256 < m ? (int)lds_class[b[u] * kRowStride + a[u]] : -1;
+      local[0] += cls == 0;
+      local[1] += cls == 1;
+      local[2] += cls == 2;
+      local[3] += cls == 3;
+    }
   }
   for (int k = 0; k < 4; ++k)
     if (local[k]) atomicAdd(&lds_counts[k], local[k]);
@@ -474,7 +487,10 @@ __device__ void count_classes(const FinalParams &P, const SeqDesc &d, int s, int
 // that produce their inputs, so the resolve half is done long before the enumeration ends.
 __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   __shared__ int lds_counts[4];
+  __shared__ __align__(4) unsigned char lds_class[kDevTable];
   const int i = blockIdx.x;
+  static_assert(kDevTable % 4 == 0 && kDevTable / 4 <= 256, "one 4-byte load per thread");
+  if (threadIdx.x < kDevTable / 4) ((uint32_t *)lds_class)[threadIdx.x] = ((const uint32_t *)P.class_t)[threadIdx.x];
   const SeqDesc d = P.desc[i];
   const SeqAcc a = P.acc[i];
   const SeqAcc ea = P.eacc[i];
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
     const bool res_ok = uni((P.stages & PSA_STAGE_RESOLVE) && a.res_loc != ~0ull && a.res_p != INT_MAX);
     if (res_ok) {
       const int p = a.res_p, q = (int)(a.res_loc >> 32), s = (int)(uint32_t)a.res_loc;
-      count_classes(P, d, s, p, q, lds_counts, r->counts);
+      count_classes(P, d, s, p, q, lds_class, lds_counts, r->counts);
       if (tid == 0) {
         r->n = p + 1;
         r->k = q + 1;
@@ -525,7 +541,7 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
     if (enum_ok) {
       const int p = (int)(0xffffffffu - (uint32_t)ea.enum_key);
       const int q = (int)(ea.enum_loc >> 32), s = (int)(uint32_t)ea.enum_loc;
-      count_classes(P, d, s, p, q, lds_counts, r->enum_counts);
+      count_classes(P, d, s, p, q, lds_class, lds_counts, r->enum_counts);
       if (tid == 0) {
         r->enum_n = p + 1;
         r->enum_k = q + 1;

@@ -10,6 +10,7 @@ the calls raise.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -217,9 +218,12 @@ class Context:
         self._h = C.c_void_p()
         _check(lib().psa_init(device, C.byref(self._h)), "psa_init")
         self.device = device
+        self._batches = weakref.WeakSet()  # a batch must not outlive its context
 
     def close(self):
         if self._h:
+            for b in list(self._batches):
+                b.close()
             lib().psa_shutdown(self._h)
             self._h = C.c_void_p()
 
@@ -270,6 +274,9 @@ class Batch:
     def __init__(self, ctx, seq2s, offset_range=None):
         self._h = C.c_void_p()
         self.ctx = ctx
+        if not ctx._h:
+            raise ValueError("the context is closed")
+        ctx._batches.add(self)
         bs = [_bytes(s) for s in seq2s]
         self.n = len(bs)
         if offset_range is None:

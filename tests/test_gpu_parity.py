@@ -289,6 +289,20 @@ def test_invalid_inputs(psa, ctx):
         ctx.set_seq1("abc")
 
 
+def test_context_closed_before_its_batches(psa):
+    """Closing a context closes the batches still open on it (a batch holds a pointer to its
+    context); a closed context takes no new batch."""
+    c = psa.Context(0)
+    c.set_seq1("ABCDEFGHABCDEFGH")
+    c.set_weights(np.array([2, 1.5, 1.1, 1.3], dtype=np.float32))
+    b = c.batch(["ABCDEF", "HGFEDCBA"])
+    b.enqueue()  # a run nobody waits for
+    c.close()
+    b.close()  # already closed with the context: nothing left to do
+    with pytest.raises(ValueError):
+        c.batch(["ABCD"])
+
+
 def test_offset_range_shards_combine(psa, ctx, oracle):
     """Long-pair mode: shards of the offset range combine to the whole-range answer."""
     seq1, seq2s = synth_problem(21, 5000, [600])
