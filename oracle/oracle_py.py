@@ -35,6 +35,12 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/Sequential Solution"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    # the reference's MPI host program bound to libpsa_hip (needs an MPI and the built library)
+    psa_lib = os.path.join(os.path.dirname(_HERE), "parallel-sequence-alignment_amd", "libpsa_hip.so")
+    mpi_home = os.environ.get("MPI_HOME", "/opt/conda")
+    if (os.path.isdir("/root/reference/Parallel Solution") and os.path.exists(psa_lib)
+            and os.path.exists(os.path.join(mpi_home, "include", "mpi.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "refhost"], stdout=subprocess.DEVNULL)
 
 
 _lib = None

@@ -393,6 +393,36 @@ def test_mpi_host_program(psa, golden, tmp_path):
         assert all(line in r.stdout for line in want)
 
 
+def test_reference_host_program_bound_to_libpsa_hip(psa, golden, tmp_path):
+    """The drop-in boundary end to end: the reference's own MPI host program (its main.c and
+    cFunctions.c compiled unmodified by oracle/Makefile, target refhost, with calc_best_score_CUDA
+    bound to psa_calc_best_score) run as the reference runs it -- mpiexec -np 2, input.txt in the
+    working directory -- must write the output.txt the compiled Sequential reference implies."""
+    import os
+    import shutil
+    import subprocess
+    from shutil import which
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "refhost_psa")
+    mpiexec = which("/opt/conda/bin/mpiexec") or which("mpiexec")
+    if mpiexec is None or not os.path.exists(exe):
+        pytest.skip("no MPI installation or oracle/_ref/refhost_psa not built (make -C oracle refhost)")
+    # inputs within the reference's fixed buffers (Seq1 < 5000, Seq2 < 3000 characters)
+    for name in ("ref_input.txt", "ref_s_input3.txt", "ref_p_input1.txt", "ref_s_input2.txt"):
+        cases = [c for c in golden if c["name"] == name]
+        if not cases:
+            continue
+        case = cases[0]
+        work = tmp_path / ("refhost_" + name)
+        work.mkdir()
+        shutil.copy(os.path.join(root, "tests", "golden", "inputs", name), work / "input.txt")
+        r = subprocess.run([mpiexec, "-np", "2", exe], capture_output=True, text=True, timeout=120, cwd=str(work))
+        assert r.returncode == 0, r.stderr + r.stdout
+        want = _expected_lines(psa, case)
+        assert open(work / "output.txt").read().splitlines(keepends=True) == want
+        assert all(line in r.stdout for line in want)  # the echo of P/cudaFunctions.cu:321
+
+
 def test_config3_shape_small(psa, ctx, oracle):
     """Batch of Seq2 of mixed lengths (every kernel variant in one launch set) against Seq1 = 10000."""
     rng = np.random.default_rng(33)
