@@ -26,7 +26,7 @@ thread_local std::string g_err;
 
 constexpr size_t kSlabUnit = 256;                 // bytes: one run of 64 int32
 constexpr size_t kSlabMinUnits = (5u << 20) / 256;  // the largest chunk (64 offsets x (2 x 128 + 1) runs) fits
-constexpr size_t kSlabDefaultMiB = 2048;
+constexpr size_t kSlabDefaultMiB = 512;  // against 2048: one long pair 1.6 % faster, a large mixed batch 1 % slower, a quarter of the memory
 
 // Device block, pinned host block and events of one batch.  A context keeps the bundles of
 // destroyed batches and hands them to new ones, so that scoring batch after batch through
