@@ -116,7 +116,7 @@ def measured_traffic(cfg, f_bytes):
     """Memory-side bytes per launch of the candidate-loop kernel as the TCC counters saw them in the
     committed rocprofv3 run of this workload (profiles/r01_c2_pmc.json); None for workloads not
     profiled.  Calibration (profiles/r01_fetch_size_calibration.txt): the kernel's scalar reads are
-    counted in full, its dword-per-lane reads of the f rows (f_bytes) at half."""
+    counted in full, its dword-per-lane reads (f of an offset: the next offset's row of g, f_bytes) at half."""
     path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
     if cfg != "c2" or not os.path.exists(path):
         return None
@@ -260,16 +260,17 @@ def main():
             # this rank's average candidate-loop kernel time per step, launches not sharing the GPU
             kern_s = (iso_enum_ms / n_iso if n_iso else enum_ms / args.steps) / 1e3
             achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
-            # slab rows the candidate loop reads: 4-byte f and g per (offset, position), once each
-            slab_bytes = sum(8.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
+            # slab rows the candidate loop reads: one 4-byte g per (offset, position); f of an offset is the
+            # next offset's row (a chunk of 4 to 64 offsets stores one row more than it has offsets: not counted)
+            slab_bytes = sum(4.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
                              for s2, r in zip(seq2s, res) if r.candidates > 0) if rng is None else \
-                8.0 * len(seq2s[0]) * (rng[1] - rng[0])
+                4.0 * len(seq2s[0]) * (rng[1] - rng[0])
             out["roofline"] = {
                 "bound": "valu-32bit", "kernel": "psa_enum_wave",
                 "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
-                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config, slab_bytes / 2),
+                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config, slab_bytes),
                 "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs, plus the half of "
-                                "the f-row reads that FETCH_SIZE does not count; Infinity-Cache hits included)",
+                                "the per-lane row reads that FETCH_SIZE does not count; Infinity-Cache hits included)",
                 "kernel_ms": kern_s * 1e3,
                 # the same launch inside the timed region, where it shares the GPU with the launch
                 # of the step before or after it (null with --sync-steps: no sharing)
@@ -282,7 +283,7 @@ def main():
                 "note": "2 lane-ops (add + max) per candidate x candidates per step / HIP-event time of the "
                         "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
                         "their stream, measured on steps launched one at a time after the timed region "
-                        "(inside it two launches share the GPU: kernel_ms_pipelined); the kernel reads 8 bytes "
+                        "(inside it two launches share the GPU: kernel_ms_pipelined); the kernel reads 4 bytes "
                         "of slab per (offset, position) against L2/2 candidates each (hbm_frac of the 8 TB/s "
                         "peak), so 32-bit VALU issue bounds it, not HBM or MFMA",
             }

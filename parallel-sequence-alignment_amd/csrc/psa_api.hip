@@ -25,7 +25,7 @@ thread_local std::string g_err;
   } while (0)
 
 constexpr size_t kSlabUnit = 256;                 // bytes: one run of 64 int32
-constexpr size_t kSlabMinUnits = (5u << 20) / 256;  // the largest chunk (64 offsets x (2 x 128 + 1) runs) fits
+constexpr size_t kSlabMinUnits = (5u << 20) / 256;  // the largest chunk (64 + 1 rows of 128 + 1 runs) fits
 constexpr size_t kSlabDefaultMiB = 512;  // against 2048: one long pair 1.6 % faster, a large mixed batch 1 % slower, a quarter of the memory
 
 // Device block, pinned host block and events of one batch.  A context keeps the bundles of
@@ -409,7 +409,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     for (int64_t s0 = d.s_begin; s0 < d.s_end; s0 += per) {
       const int64_t cnt = std::min<int64_t>(per, d.s_end - s0);
       chunks.push_back(psa::Chunk{i, (int32_t)s0, (int32_t)cnt, 0u});
-      total_units += (size_t)cnt * (2 * (size_t)runs_of(d.len2) + 1);
+      total_units += ((size_t)cnt + 1) * ((size_t)runs_of(d.len2) + 1);  // one row more than offsets, see psa_enum_prep
     }
   }
   // slab passes: consecutive chunks whose rows fit one slab
@@ -420,7 +420,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     size_t used = 0;
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
       psa::Chunk &ch = chunks[ci];
-      const size_t need = (size_t)ch.ns * (2 * (size_t)runs_of(b->desc[(size_t)ch.seq].len2) + 1);
+      const size_t need = ((size_t)ch.ns + 1) * ((size_t)runs_of(b->desc[(size_t)ch.seq].len2) + 1);
       if (b->passes.empty() || used + need > cap_units) {
         if (!b->passes.empty()) b->passes.back().c1 = (int)ci;
         b->passes.emplace_back();

@@ -14,8 +14,10 @@
 //
 // Three kernels:
 //   psa_enum_prep    one workgroup per chunk of offsets: prefix sums of the diagonals in
-//                    LDS, then one row of f and one row of g per offset into a slab in HBM
-//                    (8 bytes per position and offset, against L2/2 candidates each);
+//                    LDS, then one row of g per offset into a slab in HBM.  f needs no row of
+//                    its own: g_{s+1}[p] = E^s[p] + E^{s-1}[L2] - E^{s-1}[p+1] = f_s[p] + E^{s-1}[L2],
+//                    so a chunk of ns offsets stores ns + 1 rows of g, each with its constant
+//                    (4 bytes per position and offset, against L2/2 candidates each);
 //   psa_enum_wave    the candidate loop.  One wave per (offsets, 256 positions p): f sits
 //                    in 4 vector registers per lane, g arrives through scalar loads (it is
 //                    wave-uniform); no LDS, no barriers, so waves are scheduled one by
@@ -119,10 +121,13 @@ __device__ __forceinline__ void enum_chunk_setup(unsigned char *smem, const Enum
 }
 
 // ---- pre-pass -----------------------------------------------------------------------
-// Row of offset s in the slab: 64*nruns f values (0 beyond p = L2-2), then 64*nruns g
-// values (q = 0 repeats g[1], q >= L2 repeat g[L2-1]: duplicates of scored candidates).
-// With F32 the two values are stored as float32: the scale keeps |f| and |g| at or below 2^24,
-// so the conversion is exact.
+// Row of offset s in the slab: 64*nruns g values (q >= L2 repeat g[L2-1]: duplicates of scored
+// candidates; q = 0, which no candidate uses, holds the formula's value because f_{s-1}[0] is
+// read from it), then one run of padding whose first word is E^{s-2}[L2], the constant that
+// turns this row into f of the offset before: f_{s-1}[p] = g_s[p] - E^{s-2}[L2].  A chunk of ns
+// offsets s0 .. s0+ns-1 stores the ns + 1 rows s0 .. s0+ns.
+// With F32 the values are stored as float32: the scale keeps |f|, |g| and the constants at or
+// below 2^24, so the conversion is exact.
 template <int NT, int R, bool F32>
 __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -134,12 +139,9 @@ __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
   const int npos = 64 * ((L2 + 63) >> 6);
   int bro[R];
   int win0;
-  enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
+  enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);  // leaves diagonals s0 - 2 and s0 - 1 in the ring
   int *row = P.fg + (size_t)ch.fg_row * 64;
-  for (int s = ch.s0; s < ch.s0 + ch.ns; ++s) {
-    // the slot this scan overwrites (diagonal s-3) was last read before the scan's first barrier
-    scan_diagonal<NT, R>(smem, bro, s, win0);
-    const int *Es = ring_slot<NT, R>(smem, s);
+  for (int s = ch.s0; s <= ch.s0 + ch.ns; ++s) {
     const int *E1 = ring_slot<NT, R>(smem, s - 1);
     const int *E2 = ring_slot<NT, R>(smem, s - 2);
     const int tot2 = E2[L2];
@@ -147,14 +149,16 @@ __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
     for (int r = 0; r < R; ++r) {
       const int p = r * NT + tid;
       if (p < npos) {
-        const int qq = p < 1 ? 1 : (p > L2 - 1 ? L2 - 1 : p);
-        const int fv = (p <= L2 - 2) ? Es[p] - E1[p + 1] : 0;
+        const int qq = p > L2 - 1 ? L2 - 1 : p;
         const int gv = E1[qq] + tot2 - E2[qq + 1];
-        row[p] = F32 ? __float_as_int((float)fv) : fv;
-        row[npos + p] = F32 ? __float_as_int((float)gv) : gv;
+        row[p] = F32 ? __float_as_int((float)gv) : gv;
       }
     }
-    row += 2 * npos + 64;  // one run of padding: rows must not start a power of two apart
+    if (tid == 0) row[npos] = F32 ? __float_as_int((float)tot2) : tot2;
+    row += npos + 64;  // one run of padding: rows must not start a power of two apart
+    // diagonal s for the next row; the slot it overwrites (diagonal s - 3) was last read two
+    // rows ago, and the scan's first barrier comes after this row's reads of s - 2
+    if (s < ch.s0 + ch.ns) scan_diagonal<NT, R>(smem, bro, s, win0);
   }
 }
 
@@ -199,6 +203,7 @@ struct Cand<false> {
                  : "v"(x), "v"(y), "n"(I0));
   }
   __device__ static __forceinline__ int add(int a, int b) { return a + b; }
+  __device__ static __forceinline__ int sub(int a, int b) { return a - b; }
   __device__ static __forceinline__ int max2(int a, int b) { return max(a, b); }
   __device__ static __forceinline__ int to_int(int a) { return a; }
 };
@@ -234,6 +239,9 @@ struct Cand<true> {
   }
   __device__ static __forceinline__ int add(int a, int b) {
     return __float_as_int(__int_as_float(a) + __int_as_float(b));
+  }
+  __device__ static __forceinline__ int sub(int a, int b) {
+    return __float_as_int(__int_as_float(a) - __int_as_float(b));
   }
   __device__ static __forceinline__ int max2(int a, int b) {
     return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b)));
@@ -380,33 +388,35 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
   const int qend = 64 * nruns;           // row length
   const int qlast = (L2 + 15) & ~15;     // the candidate loop stops at the 16-value step that holds q = L2 - 1
   const int pc0 = w * R;
-  const int *__restrict__ F = fg + ((size_t)ch.fg_row + (size_t)r0 * (2 * nruns + 1)) * 64;
+  const int rowlen = qend + 64;  // a row of g and its run of padding
+  const int *__restrict__ G = fg + ((size_t)ch.fg_row + (size_t)r0 * (nruns + 1)) * 64;  // row of offset r0
   // Register r holds run pc0 + r of p; past the last run it repeats that run (its maxima are
-  // dropped below).  The per-lane loads are buffer loads: the unit's first row is the base, a
-  // scalar byte offset walks the rows, and one register per run holds the lane's byte offset
-  // within a row -- no 64-bit address arithmetic in vector registers.
-  const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc((void *)F, 0, -1, 0x00020000);
+  // dropped below).  f of an offset is the next offset's row of g minus that row's constant.
+  // The per-lane loads are buffer loads: the unit's first row is the base, a scalar byte offset
+  // walks the rows, and one register per run holds the lane's byte offset within a row -- no
+  // 64-bit address arithmetic in vector registers.
+  const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, -1, 0x00020000);
   int vb[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) vb[r] = 4 * (64 * min(pc0 + r, nruns - 1) + lane);
-  int soff = 0;  // byte offset of the current row (at most kEnumMaxNs rows of 2 * 128 + 1 runs)
+  int soff = 0;  // byte offset of the current row (at most kEnumMaxNs + 1 rows of 128 + 1 runs)
   int fn[R], acc[R][2];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff, 0);
+    fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
     acc[r][0] = acc[r][1] = Cand<F32>::lowest;
   }
+  int tn = G[rowlen + qend];  // the constant of the next row
   for (int i = r0; i < r1; ++i) {
     int f[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) f[r] = fn[r];
-    const int *__restrict__ G = F + qend;
-    const int goff = soff + 4 * qend + 4;  // g[p + 1] per lane: the diagonal's left-over pairs
-    F += 2 * qend + 64;
-    soff += 4 * (2 * qend + 64);
+    for (int r = 0; r < R; ++r) f[r] = Cand<F32>::sub(fn[r], tn);
+    const int goff = soff + 4;  // g[p + 1] per lane: the diagonal's left-over pairs
+    soff += 4 * rowlen;
     if (i + 1 < r1) {  // next offset's f values arrive while this one is scored
 #pragma unroll
-      for (int r = 0; r < R; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff, 0);
+      for (int r = 0; r < R; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
+      tn = G[2 * rowlen + qend];
     }
     int gnext[R];
 #pragma unroll
@@ -417,6 +427,7 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r][0] = Cand<F32>::max2(acc[r][0], Cand<F32>::add(f[r], gnext[r]));
     }
+    G += rowlen;
   }
   // best fixed-point score of this unit and the smallest p attaining it
   int bestv = INT_MIN;

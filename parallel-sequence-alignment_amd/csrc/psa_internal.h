@@ -37,7 +37,8 @@ struct SeqAcc {
 };
 
 // ns consecutive offsets of one Seq2: the unit of the enumeration pre-pass, which writes
-// the f and g values of those offsets as rows of the slab starting at fg_row.
+// the g values of those offsets (and of the offset after them: f of an offset is read from the
+// next offset's row) as ns + 1 rows of the slab starting at fg_row.
 struct Chunk {
   int32_t seq;
   int32_t s0;

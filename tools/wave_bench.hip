@@ -1,4 +1,4 @@
-// Times psa_enum_wave of libpsa_hip on a synthetic slab (random f/g rows), without the
+// Times psa_enum_wave of libpsa_hip on a synthetic slab (random rows of g), without the
 // rest of a run around it.
 // Build: hipcc -O3 --offload-arch=gfx950 -I../include -o wave_bench wave_bench.hip \
 //        -L../parallel-sequence-alignment_amd -lpsa_hip -Wl,-rpath,'$ORIGIN/../parallel-sequence-alignment_amd'
@@ -31,25 +31,29 @@ int main(int argc, char **argv) {
   const int lds = argc > 6 ? std::atoi(argv[6]) : 0;
   const bool f32 = argc > 7 ? std::atoi(argv[7]) != 0 : true;
   const int wpg = argc > 8 ? std::atoi(argv[8]) : 8;
-  const int nruns = (len2 + 63) / 64, stride = 128 * nruns + 64;
+  const int nruns = (len2 + 63) / 64, stride = 64 * nruns + 64;  // a row of g and its run of padding
   const int levels = (nruns + psa::kEnumWaveRuns - 1) / psa::kEnumWaveRuns;
   const int per = std::min(ens << sub_log2, psa::kEnumMaxNs);
-  std::vector<int> h((size_t)rows * stride + 64, 0);
+  // chunks of `per` offsets, each with per + 1 rows of g (f of an offset = the next row minus its constant)
+  std::vector<psa::Chunk> chunks;
+  size_t nrows = 0;
+  for (int s0 = 0; s0 < rows; s0 += per) {
+    const int cnt = std::min(per, rows - s0);
+    chunks.push_back(psa::Chunk{0, s0, cnt, (uint32_t)(nrows * (nruns + 1))});
+    nrows += (size_t)cnt + 1;
+  }
+  std::vector<int> h(nrows * stride + 64, 0);
   uint32_t x = 12345u;
   auto rnd = [&]() {
     x = x * 1664525u + 1013904223u;
     return (int)(x >> 8) % 200000 - 100000;
   };
-  for (int r = 0; r < rows; ++r) {
-    int *F = h.data() + (size_t)r * stride, *G = F + 64 * nruns;
-    for (int p = 0; p <= len2 - 2; ++p) F[p] = rnd();
-    for (int q = 1; q <= len2 - 1; ++q) G[q] = rnd();
-    G[0] = G[1];
+  for (size_t r = 0; r < nrows; ++r) {
+    int *G = h.data() + r * stride;
+    for (int q = 0; q <= len2 - 1; ++q) G[q] = rnd();
     for (int q = len2; q < 64 * nruns; ++q) G[q] = G[len2 - 1];
+    G[64 * nruns] = rnd();  // the row's constant
   }
-  std::vector<psa::Chunk> chunks;
-  for (int s0 = 0; s0 < rows; s0 += per)
-    chunks.push_back(psa::Chunk{0, s0, std::min(per, rows - s0), (uint32_t)((size_t)s0 * (2 * nruns + 1))});
   psa::SeqDesc d{};
   d.len2 = len2;
   d.s_begin = 0;
@@ -107,18 +111,19 @@ int main(int argc, char **argv) {
   // brute-force check of the overall maximum and its smallest p
   long long bv = LLONG_MIN;
   int bp = -1;
-  for (int r = 0; r < rows; ++r) {
-    const int *F = h.data() + (size_t)r * stride, *G = F + 64 * nruns;
-    int sm = INT_MIN;  // suffix maximum of g
-    for (int p = len2 - 2; p >= 0; --p) {
-      sm = std::max(sm, G[p + 1]);
-      const long long v = (long long)F[p] + sm;
-      if (v > bv || (v == bv && p < bp)) {
-        bv = v;
-        bp = p;
+  for (const psa::Chunk &ch : chunks)
+    for (int i = 0; i < ch.ns; ++i) {
+      const int *G = h.data() + ((size_t)ch.fg_row / (nruns + 1) + i) * stride, *Gn = G + stride;
+      int sm = INT_MIN;  // suffix maximum of g
+      for (int p = len2 - 2; p >= 0; --p) {
+        sm = std::max(sm, G[p + 1]);
+        const long long v = (long long)Gn[p] - Gn[64 * nruns] + sm;
+        if (v > bv || (v == bv && p < bp)) {
+          bv = v;
+          bp = p;
+        }
       }
     }
-  }
   const int gv = (int)((uint32_t)(acc.enum_key >> 32) ^ 0x80000000u), gp = (int)(0xffffffffu - (uint32_t)acc.enum_key);
   const double cand = (double)rows * ((double)len2 * (len2 - 1) / 2);
   std::printf("%s offsets=%d len2=%d enum_ns=%d sub_log2=%d units=%d lds=%d  %.4f ms  %.3e cand/s  frac=%.3f  check=%s\n", f32 ? "f32" : "i32", rows,
