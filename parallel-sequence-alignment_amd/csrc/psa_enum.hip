@@ -303,18 +303,68 @@ __device__ __forceinline__ void wave_step16(const int *g, const int (&f)[R], int
   maxima(3);
 }
 
+// The long phase's step with the scalar load of the step after it issued in its shadow: the 16
+// values of this step are waited for at their first use (the copies of the first block), the
+// next 16 are requested right behind that (scalar loads return out of order, so a wait always
+// covers every load in flight: the request must follow the wait, which the compiler barrier
+// pins), and the rest of the step covers their latency.
+template <int R, bool F32>
+__device__ __forceinline__ void wave_step16_next(const int *g, int *gn, const int *__restrict__ Gn,
+                                                 const int (&f)[R], int (&acc)[R][2]) {
+  int t[4][R][4];
+  auto sums = [&](int b) {
+    int vg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vg[i]) : "s"(g[4 * b + i]));
+    if (b == 0) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gn[i] = Gn[i];
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      t[b][r][0] = Cand<F32>::add_vv(vg[0], f[r]);
+      t[b][r][1] = Cand<F32>::add_vv(vg[1], f[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      t[b][r][2] = Cand<F32>::add_vv(vg[2], f[r]);
+      t[b][r][3] = Cand<F32>::add_vv(vg[3], f[r]);
+    }
+  };
+  auto maxima = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) Cand<F32>::max3_acc(acc[r][0], t[b][r][0], t[b][r][1]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) Cand<F32>::max3_acc(acc[r][1], t[b][r][2], t[b][r][3]);
+  };
+  sums(0);
+  sums(1);
+  maxima(0);
+  sums(2);
+  maxima(1);
+  sums(3);
+  maxima(2);
+  maxima(3);
+}
+
 // q in [qa, qb) (multiples of 16) against all R registers.  G is wave-uniform, so the 16
-// values of a step come in with one scalar load; the other waves of the SIMD cover its
-// latency.
+// values of a step come in with one scalar load, requested one step ahead.  The last request
+// of a row may reach 16 values past qb: into the row's padding at most.
 template <int R, bool F32>
 __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int qb, const int (&f)[R],
                                           int (&acc)[R][2]) {
-  for (int q = qa; q < qb; q += 16) {
-    int g[16];
+  if (qa >= qb) return;
+  int ga[16], gb[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) g[i] = G[q + i];
-    wave_step16<R, R, F32>(g, f, acc);
+  for (int i = 0; i < 16; ++i) ga[i] = G[qa + i];
+  int q = qa;
+  for (; q + 32 <= qb; q += 32) {
+    wave_step16_next<R, F32>(ga, gb, G + q + 16, f, acc);
+    wave_step16_next<R, F32>(gb, ga, G + q + 32, f, acc);
   }
+  if (q < qb) wave_step16<R, R, F32>(ga, f, acc);
 }
 
 // The q run that coincides with a register's own p run: lane l holds p = q0 + l, so
