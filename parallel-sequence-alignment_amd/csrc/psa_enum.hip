@@ -391,33 +391,40 @@ __device__ __forceinline__ void diag_group(const int *g, int f, int (&acc)[2]) {
 // scalar load each, as in the long phase: holding all 64 values of a run in scalar registers
 // left too few for the loop's own scalars, which hipcc then parked in vector-register lanes).
 template <int R, int J, int C, bool F32>
-__device__ __forceinline__ void own_chunk(const int *__restrict__ Gj, const int (&f)[R], int (&acc)[R][2]) {
-  int g[16];
+__device__ __forceinline__ void own_chunk(const int *g, int *gn, const int *__restrict__ Gn, const int (&f)[R],
+                                          int (&acc)[R][2]) {
+  // the wait for this chunk's values sits here, and the request for the next chunk's right behind it
+  asm volatile("" ::"s"(g[0]));
+  asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 16; ++i) g[i] = Gj[16 * C + i];
+  for (int i = 0; i < 16; ++i) gn[i] = Gn[i];
+  asm volatile("" ::: "memory");
   if constexpr (J > 0) wave_step16<R, J, F32>(g, f, acc);
   diag_group<16 * C, F32>(g, f[J], acc[J]);
   diag_group<16 * C + 4, F32>(g + 4, f[J], acc[J]);
   diag_group<16 * C + 8, F32>(g + 8, f[J], acc[J]);
   diag_group<16 * C + 12, F32>(g + 12, f[J], acc[J]);
 }
+// ga holds the first 16 values of run pc0 + J on entry and those of run pc0 + J + 1 on return
+// (the last request of a level reaches into the run after its own runs: the row's padding at most).
 template <int R, int J, bool F32>
 struct WaveOwn {
   __device__ static __forceinline__ void run(const int *__restrict__ G, int pc0, int nruns, const int (&f)[R],
-                                             int (&acc)[R][2]) {
-    WaveOwn<R, J - 1, F32>::run(G, pc0, nruns, f, acc);
+                                             int (&acc)[R][2], int (&ga)[16], int (&gb)[16]) {
+    WaveOwn<R, J - 1, F32>::run(G, pc0, nruns, f, acc, ga, gb);
     if (pc0 + J < nruns) {
       const int *__restrict__ Gj = G + 64 * (pc0 + J);
-      own_chunk<R, J, 0, F32>(Gj, f, acc);
-      own_chunk<R, J, 1, F32>(Gj, f, acc);
-      own_chunk<R, J, 2, F32>(Gj, f, acc);
-      own_chunk<R, J, 3, F32>(Gj, f, acc);
+      own_chunk<R, J, 0, F32>(ga, gb, Gj + 16, f, acc);
+      own_chunk<R, J, 1, F32>(gb, ga, Gj + 32, f, acc);
+      own_chunk<R, J, 2, F32>(ga, gb, Gj + 48, f, acc);
+      own_chunk<R, J, 3, F32>(gb, ga, Gj + 64, f, acc);
     }
   }
 };
 template <int R, bool F32>
 struct WaveOwn<R, -1, F32> {
-  __device__ static __forceinline__ void run(const int *__restrict__, int, int, const int (&)[R], int (&)[R][2]) {}
+  __device__ static __forceinline__ void run(const int *__restrict__, int, int, const int (&)[R], int (&)[R][2],
+                                             int (&)[16], int (&)[16]) {}
 };
 
 // One unit: sub-run j of chunk c at level w (positions p in [256 w, 256 w + 256)).
@@ -472,7 +479,13 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
 #pragma unroll
     for (int r = 0; r < R; ++r) gnext[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], goff, 0);
     wave_full<R, F32>(G, 64 * (pc0 + R), qlast, f, acc);
-    WaveOwn<R, R - 1, F32>::run(G, pc0, nruns, f, acc);
+    {
+      // the level's own runs, read as one ascending stream of 16-value steps
+      int ga[16], gb[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ga[k] = G[64 * pc0 + k];
+      WaveOwn<R, R - 1, F32>::run(G, pc0, nruns, f, acc, ga, gb);
+    }
     if ((lane & 1) == 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r][0] = Cand<F32>::max2(acc[r][0], Cand<F32>::add(f[r], gnext[r]));
