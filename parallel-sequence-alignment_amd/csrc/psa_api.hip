@@ -400,7 +400,8 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     d.enum_ns = (int32_t)std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
     min_ns = std::min(min_ns, d.enum_ns);
   }
-  int sub_log2 = min_ns >= 4 ? 0 : (min_ns >= 2 ? 1 : 2);  // chunks of at least 4 offsets
+  // chunks of at least 8 offsets: a chunk's pre-pass scans two diagonals and stores one row more than it has offsets
+  int sub_log2 = min_ns >= 8 ? 0 : (min_ns >= 4 ? 1 : (min_ns >= 2 ? 2 : 3));
   if (const char *e = std::getenv("PSA_ENUM_SUB_LOG2")) sub_log2 = std::max(0, std::min(3, std::atoi(e)));  // tuning aid
   size_t total_units = 0;
   for (int i : order) {
