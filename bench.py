@@ -8,7 +8,9 @@ One process per GPU (for N > 1 launch through torch.distributed.run).  A step is
 pass of the full path -- fixed-point enumeration of every candidate, the float32-exact
 resolve, class counts, result records -- over one batch of synthetic Seq2.  The batch
 is uploaded once before the timed region.  Ranks hold independent batches (no data-path
-collective); rank 0 prints one JSON line.
+collective); rank 0 prints one JSON line.  Before the W warm-up steps the same workload runs
+untimed for --prewarm-s seconds (default 0.5): the GPU reaches its sustained clocks only after
+tens of milliseconds of load, and the default workload's step lasts a fifth of a millisecond.
 
 Workloads (BASELINE.json configs):
   c2  Seq1 = 3000, 4 x Seq2 = 2000              (default; the metric's configuration)
