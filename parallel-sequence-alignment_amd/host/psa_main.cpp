@@ -9,6 +9,7 @@
 // node with a cost-based split.
 //
 //   psa_host [input.txt [output.txt [ngpus]]]
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,7 @@ int main(int argc, char **argv) {
 
   std::vector<psa_result> results((size_t)n);
   std::vector<int> worker_status((size_t)ngpu, PSA_OK);
+  std::vector<std::string> worker_error((size_t)ngpu);  // the library's error text is per thread
   std::vector<std::thread> workers;
   for (int g = 0; g < ngpu; ++g) {
     workers.emplace_back([&, g]() {
@@ -93,6 +95,7 @@ int main(int argc, char **argv) {
       if (st == PSA_OK)
         for (size_t k = 0; k < idx.size(); ++k) results[(size_t)idx[k]] = r[k];
       worker_status[(size_t)g] = st;
+      if (st != PSA_OK) worker_error[(size_t)g] = psa_last_error_text();
       psa_shutdown(ctx);
     });
   }
@@ -100,7 +103,7 @@ int main(int argc, char **argv) {
   for (int g = 0; g < ngpu; ++g)
     if (worker_status[(size_t)g] != PSA_OK) {
       std::fprintf(stderr, "psa_host: GPU %d: %s (%s)\n", g, psa_strerror(worker_status[(size_t)g]),
-                   psa_last_error_text());
+                   worker_error[(size_t)g].c_str());
       return EXIT_FAILURE;  // the reference exits on device errors, P/cudaFunctions.cu:5-18
     }
   for (int i = 0; i < n; ++i) {
@@ -109,6 +112,10 @@ int main(int argc, char **argv) {
       return EXIT_FAILURE;
     }
     char *line = psa_format_result(&results[(size_t)i]);
+    if (!line) {
+      std::fprintf(stderr, "psa_host: out of memory\n");
+      return EXIT_FAILURE;
+    }
     std::printf("%s", line);
     std::fprintf(out, "%s", line);  // P/cFunctions.c:45
     std::free(line);
