@@ -7,22 +7,38 @@ candidates per second, whole job, inputs resident in HBM.
 One process per GPU (for N > 1 launch through torch.distributed.run).  A step is one
 pass of the full path -- fixed-point enumeration of every candidate, the float32-exact
 resolve, class counts, result records -- over one batch of synthetic Seq2.  The batch
-is uploaded once before the timed region.  Ranks hold independent batches (no data-path
-collective); rank 0 prints one JSON line.  Before the W warm-up steps the same workload runs
-untimed for --prewarm-s seconds (default 0.5): the GPU reaches its sustained clocks only after
-tens of milliseconds of load, and the default workload's step lasts a fifth of a millisecond.
+is uploaded once before the timed region.  Rank 0 prints one JSON line.  Before the W
+warm-up steps the same workload runs untimed for --prewarm-s seconds (default 0.5): the GPU
+reaches its sustained clocks only after tens of milliseconds of load, and the default
+workload's step lasts a fifth of a millisecond.
 
 Workloads (BASELINE.json configs):
-  c2  Seq1 = 3000, 4 x Seq2 = 2000              (default; the metric's configuration)
-  c1  the reference's own input.txt             (Seq1 = 1489; Seq2 = 138, 1202, 466, 377)
-  c3  Seq1 = 10000, --nseq2 Seq2 of 500..2000   (4096 in BASELINE; default 256 here per rank)
-  c4  Seq1 = 200000, Seq2 = 8000, offsets sharded over the ranks
+  c2  Seq1 = 3000, 4 x Seq2 = 2000 per GPU      (default; the metric's configuration; each rank
+                                                 holds its own batch: weak scaling)
+  c1  the reference's own input.txt             (Seq1 = 1489; Seq2 = 138, 1202, 466, 377) per GPU
+  c3  Seq1 = 10000, ONE list of --nseq2 Seq2 of 500..2000 characters (4096 in BASELINE), divided
+      among the ranks by psa_partition as the reference divides its list between its two ranks
+      (P/main.c:62-76): strong scaling, no data-path collective, records gathered to rank 0
+  c4  Seq1 = 200000, Seq2 = 8000, offsets sharded over the ranks; every step ends with the
+      all-gather of one record per rank and the max-loc combine, inside the timed region
+
+The default run (c2) also carries a `scale` block: c3 at full size and c4, a few steps each, on
+the same N ranks, so that runs at N = 1, 2, 4, 8 give strong-scaling curves for both
+(--no-scale skips it).
+
+Parity gate: after the timed region every record of c1/c2, a seeded sample of 32 records of c3
+and the record of c4 are compared with the CPU oracle (float32 answer, fixed-point enumeration,
+class counts, and the rigorous bound that ties the two), and at N > 1 the N-rank records of
+c3/c4 with what rank 0 computes alone.  On a mismatch the JSON says "parity": false and the
+exit status is 1.  The oracle is used here as a checker and, in cpu_baseline, as the timed CPU
+port; never on the measured path.
 """
 import argparse
 import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -60,34 +76,75 @@ def synth(seed, L1, L2s):
     return seq1, out
 
 
-def make_workload(cfg, rank, world, nseq2):
-    """Returns (name, seq1, seq2 list, offset range or None, description dict)."""
-    if cfg == "c2":
-        seq1, seq2s = synth(2 + 1000 * rank, 3000, [2000] * 4)
-        return "C2: Seq1=3000, 4 x Seq2=2000 per GPU", seq1, seq2s, None
-    if cfg == "c1":
-        import psa_amd
-        w, seq1, seq2s = psa_amd.readFromFile(os.path.join(ROOT, "tests", "golden", "inputs", "ref_input.txt"))
-        return "C1: reference input.txt (Seq1=1489; Seq2=138,1202,466,377) per GPU", seq1, seq2s, None
-    if cfg == "c3":
-        rng = np.random.default_rng(3 + 1000 * rank)
-        lens = [int(x) for x in rng.integers(500, 2001, size=nseq2)]
-        seq1, seq2s = synth(3 + 1000 * rank, 10000, lens)
-        return "C3: Seq1=10000, %d x Seq2 in [500,2000] per GPU" % nseq2, seq1, seq2s, None
-    if cfg == "c4":
-        seq1, seq2s = synth(4, 200000, [8000])
-        S = 200000 - 8000 + 3
-        lo, hi = S * rank // world, S * (rank + 1) // world
-        return "C4: Seq1=200000, Seq2=8000, offsets sharded over %d GPU(s)" % world, seq1, seq2s, (lo, hi)
-    raise SystemExit("unknown config " + cfg)
+def c3_list(nseq2):
+    """The one seeded list of the c3 workload (the same on every rank)."""
+    rng = np.random.default_rng(3)
+    lens = [int(x) for x in rng.integers(500, 2001, size=nseq2)]
+    return synth(3, 10000, lens)
+
+
+# ---------------------------------------------------------------------------------------------
+# the CPU oracle: checker and timed CPU port (nothing else in this file touches oracle/)
+# ---------------------------------------------------------------------------------------------
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    return oracle_py
+
+
+def check_record(oracle, seq1, seq2, table, r, stages, s_begin=0, s_end=None):
+    """One record against the oracle; returns a list of complaints (empty = bit-exact)."""
+    bad = []
+    L2 = len(seq2)
+    m = L2 - 2
+    if r.status != 0:
+        return ["status %d" % r.status]
+    if stages & 2:
+        o = oracle.fast(seq1, seq2, table, s_begin, s_end)
+        if r.key() != o.as_tuple():
+            bad.append("float32 answer %r != oracle %r" % (r.key(), o.as_tuple()))
+        elif tuple(r.counts) != oracle.counts(seq1, seq2, r.offset, r.n, r.k) or r.mutant_num != o.mutant_num:
+            bad.append("class counts / mutant number")
+    if stages & 1:
+        fr, itab, exact = oracle.fixed_table(table, L2)
+        if (r.enum_frac_bits, r.enum_exact) != (fr, exact):
+            bad.append("fixed-point scale %r != oracle %r" % ((r.enum_frac_bits, r.enum_exact), (fr, exact)))
+        elif fr >= 0:
+            e = oracle.enum_best(seq1, seq2, itab, s_begin, s_end)
+            if r.enum_key() != (e.n, e.k, e.offset, e.score):
+                bad.append("enumeration %r != oracle %r" % (r.enum_key(), (e.n, e.k, e.offset, e.score)))
+            elif tuple(r.enum_counts) != oracle.counts(seq1, seq2, e.offset, e.n, e.k):
+                bad.append("enumeration class counts")
+            if stages & 2 and not bad:
+                # the enumerated maximum and the float32 answer are the same quantity up to rounding:
+                # |fl(score) - E 2^-r| <= b for one candidate, b = gamma_{m-1} sum|x| + m 2^-(r+1)
+                u = 2.0 ** -24
+                tmax = float(np.abs(table).max())
+                b = (m - 1) * u / (1 - (m - 1) * u) * m * tmax + m * 2.0 ** -(fr + 1)
+                if abs(float(r.score) - r.enum_score * 2.0 ** -fr) > b:
+                    bad.append("float32 maximum and fixed-point maximum differ by more than the rounding bound")
+                ef = oracle.enum_score(seq1, seq2, itab, r.offset, r.n, r.k)
+                if (r.enum_score - ef) * 2.0 ** -fr > 2 * b or ef > r.enum_score:
+                    bad.append("the float32 winner's fixed-point score is not within 2b of the enumerated maximum")
+    return bad
+
+
+def check_records(seq1, seq2s, results, stages, ranges=None, threads=16):
+    """Records against the oracle, in a thread pool (the oracle calls release the GIL)."""
+    oracle = _oracle()
+    table = oracle.comp_matrix(WEIGHTS)
+    ranges = ranges or [(0, None)] * len(seq2s)
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(seq2s)))) as ex:
+        outs = list(ex.map(lambda a: check_record(oracle, seq1, a[0], table, a[1], stages, a[2][0], a[2][1]),
+                           zip(seq2s, results, ranges)))
+    return [(i, b) for i, b in enumerate(outs) if b]
 
 
 def cpu_baseline(seq1, seq2, budget_s=12.0):
     """Host-CPU baseline: the oracle's literal restatement of the reference's Sequential Solution
     (same triple loop, float32) on a bounded sample -- all offsets x a run of consecutive mutants of
     one Seq2 of the workload -- single-threaded like the reference, and on all host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_py
+    oracle_py = _oracle()
     table = oracle_py.comp_matrix(WEIGHTS)
     L1, L2 = len(seq1), len(seq2)
     S, M = L1 - L2 + 3, L2 * (L2 - 1) // 2
@@ -116,18 +173,319 @@ def cpu_baseline(seq1, seq2, budget_s=12.0):
 
 def measured_traffic(cfg, f_bytes):
     """Memory-side bytes per launch of the candidate-loop kernel as the TCC counters saw them in the
-    committed rocprofv3 run of this workload (profiles/r01_c2_pmc.json); None for workloads not
-    profiled.  Calibration (profiles/r01_fetch_size_calibration.txt): the kernel's scalar reads are
+    committed rocprofv3 run of this workload (profiles/r02_c2_pmc.json, else r01); None for workloads
+    not profiled.  Calibration (profiles/r01_fetch_size_calibration.txt): the kernel's scalar reads are
     counted in full, its dword-per-lane reads (f of an offset: the next offset's row of g, f_bytes) at half."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-    if cfg != "c2" or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        kernels = json.load(f)["kernels"]
-    for name, c in kernels.items():
-        if "psa_enum_wave" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 + 0.5 * f_bytes
-    return None
+    if cfg != "c2":
+        return None, None
+    for name in ("r02_c2_pmc.json", "r01_c2_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        for kname, c in kernels.items():
+            if "psa_enum_wave" in kname and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 + 0.5 * f_bytes, "profiles/" + name
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# one workload on the ranks of this job
+# ---------------------------------------------------------------------------------------------
+class Job:
+    """Process-group plumbing shared by the workloads."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:  # gloo: rehearsal of the N > 1 logic where the ranks cannot each have a GPU of their own
+                dist.init_process_group(args.backend)
+            self.dist = dist
+        self.backend = args.backend
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def gather_objects(self, obj):
+        """obj of every rank, in rank order, on every rank (small control data, never the data path)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def allgather_bytes(self):
+        from psa_amd import dist as pdist
+        return pdist.allgather_bytes() if self.dist is not None else None
+
+
+def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_steps):
+    """Runs one workload; returns a dict with the timing, the records and the parity verdict."""
+    import psa_amd
+    from psa_amd import dist as pdist
+    rank, world = job.rank, job.world
+    stages = {"both": psa_amd.STAGE_BOTH, "enumerate": psa_amd.STAGE_ENUMERATE,
+              "resolve": psa_amd.STAGE_RESOLVE}[args.stages]
+    mine = None          # c3: indices of the list this rank scores
+    shard = None         # c4: this rank's offsets
+    if cfg == "c2":
+        seq1, seq2s = synth(2 + 1000 * rank, 3000, [2000] * 4)
+        name, scaling, my_seq2 = "C2: Seq1=3000, 4 x Seq2=2000 per GPU", "weak", seq2s
+    elif cfg == "c1":
+        _, seq1, seq2s = psa_amd.readFromFile(os.path.join(ROOT, "tests", "golden", "inputs", "ref_input.txt"))
+        name, scaling, my_seq2 = "C1: reference input.txt (Seq1=1489; Seq2=138,1202,466,377) per GPU", "weak", seq2s
+    elif cfg == "c3":
+        # rank 0 makes the list and hands it out, as the reference's rank 0 reads input.txt and sends
+        # the sequences (P/main.c:43-76); every rank then computes the same split
+        payload = [c3_list(nseq2) if rank == 0 else None]
+        if job.dist is not None:
+            job.dist.broadcast_object_list(payload, src=0)
+        seq1, seq2s = payload[0]
+        owner = psa_amd.partition([len(s) for s in seq2s], len(seq1), world, stages)
+        mine = [i for i in range(len(seq2s)) if owner[i] == rank]
+        my_seq2 = [seq2s[i] for i in mine]
+        name = "C3: Seq1=10000, one list of %d Seq2 in [500,2000] split over %d GPU(s) by psa_partition" % (nseq2, world)
+        scaling = "strong"
+    elif cfg == "c4":
+        seq1, seq2s = synth(4, 200000, [8000])
+        S = len(seq1) - len(seq2s[0]) + 3
+        shard = pdist.offset_shard(S, rank, world)
+        my_seq2 = seq2s
+        name = "C4: Seq1=200000, Seq2=8000, offsets sharded over %d GPU(s), all-gather + max-loc combine per step" % world
+        scaling = "strong"
+    else:
+        raise SystemExit("unknown config " + cfg)
+
+    ctx.set_seq1(seq1)
+    ctx.set_weights(WEIGHTS)
+    batch = ctx.batch(my_seq2) if shard is None else ctx.batch_range(my_seq2[0], shard[0], shard[1])
+    gather_cb = job.allgather_bytes()
+    combined = [None]
+
+    def step_sync():
+        if shard is None:
+            batch.launch(stages)
+        else:  # the collective and the combine belong to the step
+            combined[0] = batch.run_allgather(world, gather_cb, stages)
+
+    pipelined = shard is None and not sync_steps
+    # clock ramp: the same work, untimed, until the GPU has been busy for prewarm_s seconds
+    t_pre = time.perf_counter()
+    batch.launch(stages)
+    group = max(1, min(20, int(0.005 / max(time.perf_counter() - t_pre, 1e-6)))) if pipelined else 1
+    while time.perf_counter() - t_pre < prewarm_s:
+        for _ in range(group):
+            batch.enqueue(stages)
+        batch.wait()
+    for _ in range(warmup):
+        step_sync()
+    job.barrier()
+    t0 = time.perf_counter()
+    enum_ms = gpu_ms = 0.0
+    if not pipelined:
+        for _ in range(steps):
+            step_sync()  # returns when the step's kernels (and for c4 the exchange) have finished
+            em, tm = batch.timing()
+            enum_ms += em
+            gpu_ms += tm
+    else:
+        # the K steps are enqueued back to back (they execute in order on the context's streams) and
+        # awaited once: the host's launch latency overlaps the previous step instead of idling the GPU
+        for _ in range(steps):
+            batch.enqueue(stages)
+        batch.wait()
+        em, tm = batch.timing()  # HIP events of the last step
+        enum_ms, gpu_ms = em * steps, tm * steps
+    my_elapsed = time.perf_counter() - t0
+    job.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # Duration of the candidate-loop kernel on its own.  In a pipelined timed region two of its
+    # launches (consecutive steps) share the GPU, so the dispatch events of one launch span more
+    # than its own work; here every step is awaited before the next is launched (its own
+    # pre-pass, resolve chain and records still run beside it).  Outside the timed region.
+    iso_enum_ms = iso_gpu_ms = 0.0
+    n_iso = max(1, min(steps, 10)) if pipelined else 0
+    for _ in range(n_iso):
+        batch.launch(stages)
+        em, tm = batch.timing()
+        iso_enum_ms += em
+        iso_gpu_ms += tm
+    job.torch.cuda.synchronize()
+
+    res = batch.results()
+    bad_status = [r.status for r in res if r.status != 0]
+    if bad_status:
+        raise SystemExit("workload has invalid Seq2: %r" % bad_status)
+    cand_rank = sum(r.candidates for r in res)
+    per_rank = job.gather_objects((my_elapsed, elapsed, cand_rank))
+    elapsed = max(p[1] for p in per_rank)
+    cand_total = float(sum(p[2] for p in per_rank))
+
+    # ---- parity gate -------------------------------------------------------------------------
+    complaints = []
+    checked = 0
+    if cfg in ("c1", "c2"):
+        mine_bad = check_records(seq1, my_seq2, res, stages)
+        checked = len(res)
+        for rk, b in enumerate(job.gather_objects(mine_bad)):
+            complaints += ["rank %d Seq2 #%d: %s" % (rk, i, "; ".join(x)) for i, x in b]
+        answer = res
+    elif cfg == "c3":
+        allrec = pdist.gather_results(res, mine, len(seq2s)) if job.dist is not None else res
+        answer = allrec
+        if rank == 0:
+            rng = np.random.default_rng(33)
+            sample = sorted(int(i) for i in rng.choice(len(seq2s), size=min(32, len(seq2s)), replace=False))
+            bad = check_records(seq1, [seq2s[i] for i in sample], [allrec[i] for i in sample], stages)
+            complaints += ["Seq2 #%d: %s" % (sample[i], "; ".join(x)) for i, x in bad]
+            checked = len(sample)
+            if sum(r.candidates for r in allrec) != sum((len(seq1) - len(s) + 3) * (len(s) * (len(s) - 1) // 2)
+                                                        for s in seq2s):
+                complaints.append("candidate count of the gathered records")
+        if world > 1:
+            # the N-rank records against what one rank computes for the whole list (rank 0, alone, untimed)
+            batch.close()
+            job.barrier()
+            if rank == 0:
+                whole = ctx.score_batch(seq2s, stages)
+                diff = [i for i, (a, b) in enumerate(zip(allrec, whole))
+                        if bytes(a) != bytes(b)]
+                if diff:
+                    complaints.append("%d of %d records differ between %d ranks and one rank (first: #%d)"
+                                      % (len(diff), len(whole), world, diff[0]))
+            job.barrier()
+    else:  # c4
+        answer = [combined[0] if combined[0] is not None else res[0]]
+        if rank == 0:
+            bad = check_records(seq1, my_seq2, answer, stages)
+            complaints += ["combined record: %s" % "; ".join(x) for _, x in bad]
+            checked = 1
+        if world > 1:
+            keys = job.gather_objects(bytes(answer[0]))
+            if any(k != keys[0] for k in keys):
+                complaints.append("the ranks returned different combined records")
+            batch.close()
+            job.barrier()
+            if rank == 0:
+                whole = ctx.score_batch(my_seq2, stages)[0]
+                if (whole.key(), whole.enum_key(), tuple(whole.counts), whole.candidates) != \
+                        (answer[0].key(), answer[0].enum_key(), tuple(answer[0].counts), answer[0].candidates):
+                    complaints.append("combined record of %d shards differs from the one-rank record" % world)
+            job.barrier()
+    batch.close()
+    parity_flags = job.gather_objects(not complaints)
+    parity = all(parity_flags)
+
+    out = {
+        "name": name, "scaling": scaling, "elapsed": elapsed, "steps": steps, "cand_total": cand_total,
+        "cand_rank": cand_rank, "per_rank": per_rank, "answer": answer, "parity": parity, "complaints": complaints,
+        "parity_checked": checked, "enum_ms": enum_ms, "gpu_ms": gpu_ms, "iso_enum_ms": iso_enum_ms,
+        "iso_gpu_ms": iso_gpu_ms, "n_iso": n_iso, "pipelined": pipelined, "stages": stages,
+        "seq1": seq1, "seq2s": seq2s, "my_seq2": my_seq2, "res": res, "shard": shard,
+    }
+    return out
+
+
+def roofline_block(cfg, w):
+    """Roofline of the candidate-loop kernel for this rank's share of the workload."""
+    steps, cand_rank = w["steps"], w["cand_rank"]
+    # this rank's average candidate-loop kernel time per step, launches not sharing the GPU
+    kern_s = (w["iso_enum_ms"] / w["n_iso"] if w["n_iso"] else w["enum_ms"] / steps) / 1e3
+    achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
+    # slab rows the candidate loop reads: one 4-byte g per (offset, position); f of an offset is the
+    # next offset's row (a chunk of 4 to 64 offsets stores one row more than it has offsets: not counted)
+    if w["shard"] is None:
+        slab_bytes = sum(4.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
+                         for s2, r in zip(w["my_seq2"], w["res"]) if r.candidates > 0)
+    else:
+        slab_bytes = 4.0 * len(w["my_seq2"][0]) * (w["shard"][1] - w["shard"][0])
+    traffic, traffic_src = measured_traffic(cfg, slab_bytes)
+    my_elapsed = w["per_rank"][0][0]
+    return {
+        "bound": "valu-32bit", "kernel": "psa_enum_wave",
+        "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
+        "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": traffic,
+        "traffic_unit": "bytes per launch from the committed rocprofv3 --pmc passes of this command (%s: FETCH_SIZE + "
+                        "WRITE_SIZE, plus the half of the per-lane row reads that FETCH_SIZE does not count; "
+                        "Infinity-Cache hits included); a constant read from that file, not measured by this run"
+                        % traffic_src if traffic is not None else None,
+        "kernel_ms": kern_s * 1e3,
+        # the same launch inside the timed region, where it shares the GPU with the launch
+        # of the step before or after it (null when steps are awaited one by one: no sharing)
+        "kernel_ms_pipelined": w["enum_ms"] / steps if w["pipelined"] else None,
+        # the same fraction with the whole step in the denominator (pre-pass, locate,
+        # records and every gap included)
+        "step_frac": cand_rank * OPS_PER_CANDIDATE * steps / my_elapsed / PEAK_INT32_LANE_OPS,
+        "hbm_bytes_algorithmic": slab_bytes,
+        "hbm_frac": slab_bytes / kern_s / 8.0e12,
+        "note": "2 lane-ops (add + max) per candidate x candidates per step / HIP-event time of the "
+                "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
+                "their stream, measured on steps launched one at a time after the timed region "
+                "(inside it two launches share the GPU: kernel_ms_pipelined); the kernel reads 4 bytes "
+                "of slab per (offset, position) against L2/2 candidates each (hbm_frac of the 8 TB/s "
+                "peak), so 32-bit VALU issue bounds it, not HBM or MFMA",
+    }
+
+
+def host_inclusive(ctx, seq1, seq2s, calls=20):
+    """The same work through the calls a host program makes, host buffers in and records out
+    (work lists rebuilt and uploaded per call): never the headline value."""
+    import psa_amd
+    ctx.set_seq1(seq1)
+    ctx.set_weights(WEIGHTS)
+    out = {}
+    cand = sum((len(seq1) - len(s) + 3) * (len(s) * (len(s) - 1) // 2) for s in seq2s)
+    for label, st in (("psa_score_batch_both_stages", psa_amd.STAGE_BOTH),
+                      ("psa_score_batch_resolve_only", psa_amd.STAGE_RESOLVE)):
+        ctx.score_batch(seq2s, st)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            ctx.score_batch(seq2s, st)
+        ms = 1e3 * (time.perf_counter() - t0) / calls
+        out[label] = {"ms_per_call": ms, "candidates_per_s": cand / ms * 1e3}
+    os.environ["PSA_SHIM_QUIET"] = "1"
+    table = psa_amd.createCompMatrix(WEIGHTS)
+    psa_amd.calc_best_score(seq1, seq2s[0], table)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        for s in seq2s:
+            psa_amd.calc_best_score(seq1, s, table)
+    out["psa_calc_best_score"] = {"ms_per_seq2": 1e3 * (time.perf_counter() - t0) / (calls * len(seq2s)),
+                                  "note": "the drop-in for calc_best_score_CUDA, one Seq2 per call, resolve stage"}
+    return out
+
+
+def scale_entry(w, world):
+    """The strong-scaling figures of one workload of the scale block."""
+    return {"workload": w["name"], "scaling": w["scaling"], "value": w["cand_total"] * w["steps"] / w["elapsed"],
+            "unit": "candidates/s", "ms_per_step": 1e3 * w["elapsed"] / w["steps"], "steps": w["steps"],
+            "n_ranks_seen": len(w["per_rank"]), "candidates_per_step": w["cand_total"],
+            "per_rank_candidates": [p[2] for p in w["per_rank"]],
+            # each rank's own time for its steps, before the closing barrier: the imbalance of the split
+            "per_rank_ms_per_step": [1e3 * p[0] / w["steps"] for p in w["per_rank"]],
+            "imbalance_max_over_mean": max(p[0] for p in w["per_rank"]) / (sum(p[0] for p in w["per_rank"]) / world),
+            "parity": w["parity"], "parity_checked_records": w["parity_checked"],
+            "result_sample": {"n": w["answer"][0].n, "k": w["answer"][0].k, "offset": w["answer"][0].offset,
+                              "score_bits": "0x%08x" % w["answer"][0].score_bits} if w["answer"] else None}
 
 
 def main():
@@ -141,175 +499,80 @@ def main():
                          "sustained clocks only after tens of milliseconds of load (a 5 ms timed region on an idle GPU "
                          "measures the ramp: 0.27 instead of 0.22 ms per C2 step)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4"])
-    ap.add_argument("--nseq2", type=int, default=256, help="Seq2 per GPU for --config c3")
+    ap.add_argument("--nseq2", type=int, default=4096, help="length of the Seq2 list of --config c3 (whole job)")
     ap.add_argument("--stages", default="both", choices=["both", "enumerate", "resolve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale", action="store_true", help="skip the scale block (c3 and c4) of the default run")
+    ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="wait for every step before launching the next")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"c1": 200, "c2": 200, "c3": 5, "c4": 3}[args.config]
+        args.steps = {"c1": 200, "c2": 200, "c3": 3, "c4": 3}[args.config]
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:  # gloo: rehearsal of the N > 1 logic where the ranks cannot each have a GPU of their own
-            dist.init_process_group(args.backend)
-    cdev = "cuda" if args.backend == "nccl" else "cpu"  # where the few collective payloads live
-
+    job = Job(args)
+    rank, world = job.rank, job.world
     import psa_amd
-    name, seq1, seq2s, rng = make_workload(args.config, rank, world, args.nseq2)
-    ctx = psa_amd.Context(local_rank)
-    ctx.set_seq1(seq1)
-    ctx.set_weights(WEIGHTS)
-    batch = ctx.batch(seq2s) if rng is None else ctx.batch_range(seq2s[0], rng[0], rng[1])
-    stages = {"both": psa_amd.STAGE_BOTH, "enumerate": psa_amd.STAGE_ENUMERATE,
-              "resolve": psa_amd.STAGE_RESOLVE}[args.stages]
+    ctx = psa_amd.Context(job.local_rank)
+    w = run_workload(job, ctx, args, args.config, args.steps, args.warmup, args.prewarm_s, args.nseq2, args.sync_steps)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    scale = None
+    if args.config == "c2" and not args.no_scale:
+        # strong scaling of the two sharded workloads on the same ranks: few steps, full sizes
+        scale = {}
+        for cfg, steps in (("c3", 2), ("c4", 3)):
+            ws = run_workload(job, ctx, args, cfg, steps, 1, 0.0, 4096, False)
+            scale[cfg] = scale_entry(ws, world)
+            scale[cfg]["complaints"] = ws["complaints"][:5]
+        scale["note"] = ("c3 = BASELINE's list of 4096 Seq2 divided among the ranks by psa_partition (no data-path "
+                         "collective, records gathered to rank 0 and compared with a one-rank run); c4 = one pair, "
+                         "offsets sharded, one all-gather of a 96-byte record per rank and the max-loc combine "
+                         "inside every timed step; strong scaling: compare `value` across runs with different --gpus")
 
-    # clock ramp: the same work, untimed, until the GPU has been busy for --prewarm-s seconds
-    t_pre = time.perf_counter()
-    batch.launch(stages)
-    group = 1 if args.sync_steps else max(1, min(20, int(0.005 / max(time.perf_counter() - t_pre, 1e-6))))
-    while time.perf_counter() - t_pre < args.prewarm_s:
-        for _ in range(group):
-            batch.enqueue(stages)
-        batch.wait()
-    for _ in range(args.warmup):
-        batch.launch(stages)
-    barrier()
-    t0 = time.perf_counter()
-    enum_ms = gpu_ms = 0.0
-    if args.sync_steps:
-        for _ in range(args.steps):
-            batch.launch(stages)  # returns when the step's kernels and the record copy have finished
-            em, tm = batch.timing()
-            enum_ms += em
-            gpu_ms += tm
-    else:
-        # the K steps are enqueued back to back (they execute in order on the context's streams) and
-        # awaited once: the host's launch latency overlaps the previous step instead of idling the GPU
-        for _ in range(args.steps):
-            batch.enqueue(stages)
-        batch.wait()
-        em, tm = batch.timing()  # HIP events of the last step
-        enum_ms, gpu_ms = em * args.steps, tm * args.steps
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # Duration of the candidate-loop kernel on its own.  In the timed region above two of its
-    # launches (consecutive steps) share the GPU, so the dispatch events of one launch span more
-    # than its own work; here every step is awaited before the next is launched (its own
-    # pre-pass, resolve chain and records still run beside it).  Outside the timed region.
-    iso_enum_ms = iso_gpu_ms = 0.0
-    n_iso = 0 if args.sync_steps else max(1, min(args.steps, 10))
-    for _ in range(n_iso):
-        batch.launch(stages)
-        em, tm = batch.timing()
-        iso_enum_ms += em
-        iso_gpu_ms += tm
-    torch.cuda.synchronize()
-
-    res = batch.results()
-    bad = [r.status for r in res if r.status != 0]
-    if bad:
-        raise SystemExit("workload has invalid Seq2: %r" % bad)
-    cand_rank = sum(r.candidates for r in res)
-    if dist is not None:
-        t = torch.tensor([elapsed, float(cand_rank)], dtype=torch.float64, device=cdev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, cand_total = float(tmax[0]), float(tsum[1])
-        if args.config == "c4":  # one long pair: the job's answer is the max-loc combine of the shards
-            rec = np.frombuffer(bytes(res[0]), dtype=np.uint8).copy()
-            mine = torch.from_numpy(rec).to(cdev)
-            allrec = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allrec, mine)
-            parts = [psa_amd.Result.from_buffer_copy(bytes(x.cpu().numpy())) for x in allrec]
-            res = [psa_amd.combine_results(parts)]
-    else:
-        cand_total = float(cand_rank)
-
+    parity = w["parity"] and (scale is None or all(scale[c]["parity"] for c in ("c3", "c4")))
     if rank == 0:
         # float32 throughout by default (the enumeration on integer-valued float32, the resolve on the reference's sums)
         enum_dtype = "i32+f32" if os.environ.get("PSA_ENUM_I32", "0") not in ("", "0") else "f32"
-        value = cand_total * args.steps / elapsed
+        res0 = w["answer"][0]
         out = {
             "metric": "scored (offset,mutant) candidates/sec",
-            "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "value": w["cand_total"] * w["steps"] / w["elapsed"], "unit": "candidates/s", "n_gpus": world,
+            "steps": w["steps"], "warmup": args.warmup,
+            "ms_per_step": 1e3 * w["elapsed"] / w["steps"],
             # first kernel start to last kernel end of one step run on its own (HIP events)
-            "gpu_ms_per_step_alone": (iso_gpu_ms / n_iso) if n_iso else gpu_ms / args.steps,
+            "gpu_ms_per_step_alone": (w["iso_gpu_ms"] / w["n_iso"]) if w["n_iso"] else w["gpu_ms"] / w["steps"],
             "higher_is_better": True,
-            "scaling": "strong" if args.config == "c4" else "weak",
+            "scaling": w["scaling"],
             "vs_baseline": None, "dtype": enum_dtype, "data": "synthetic"
             if args.config != "c1" else "reference sample input",
-            "config": {"workload": name, "stages": args.stages, "weights": [float(x) for x in WEIGHTS],
-                       "candidates_per_step": cand_total, "seed": "2 + 1000*rank", "prewarm_s": args.prewarm_s},
-            "result_sample": {"n": res[0].n, "k": res[0].k, "offset": res[0].offset,
-                              "score_bits": "0x%08x" % res[0].score_bits, "enum_n": res[0].enum_n,
-                              "enum_k": res[0].enum_k, "enum_offset": res[0].enum_offset},
+            "parity": parity,
+            "parity_detail": {"records_checked_against_oracle": w["parity_checked"] * (world if args.config in ("c1", "c2") else 1),
+                              "complaints": w["complaints"][:5]},
+            "config": {"workload": w["name"], "stages": args.stages, "weights": [float(x) for x in WEIGHTS],
+                       "candidates_per_step": w["cand_total"], "prewarm_s": args.prewarm_s,
+                       "per_rank_ms_per_step": [1e3 * p[0] / w["steps"] for p in w["per_rank"]]},
+            "result_sample": {"n": res0.n, "k": res0.k, "offset": res0.offset,
+                              "score_bits": "0x%08x" % res0.score_bits, "enum_n": res0.enum_n,
+                              "enum_k": res0.enum_k, "enum_offset": res0.enum_offset},
         }
-        if stages & psa_amd.STAGE_ENUMERATE and enum_ms > 0:
-            # this rank's average candidate-loop kernel time per step, launches not sharing the GPU
-            kern_s = (iso_enum_ms / n_iso if n_iso else enum_ms / args.steps) / 1e3
-            achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
-            # slab rows the candidate loop reads: one 4-byte g per (offset, position); f of an offset is the
-            # next offset's row (a chunk of 4 to 64 offsets stores one row more than it has offsets: not counted)
-            slab_bytes = sum(4.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
-                             for s2, r in zip(seq2s, res) if r.candidates > 0) if rng is None else \
-                4.0 * len(seq2s[0]) * (rng[1] - rng[0])
-            out["roofline"] = {
-                "bound": "valu-32bit", "kernel": "psa_enum_wave",
-                "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
-                "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": measured_traffic(args.config, slab_bytes),
-                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs, plus the half of "
-                                "the per-lane row reads that FETCH_SIZE does not count; Infinity-Cache hits included)",
-                "kernel_ms": kern_s * 1e3,
-                # the same launch inside the timed region, where it shares the GPU with the launch
-                # of the step before or after it (null with --sync-steps: no sharing)
-                "kernel_ms_pipelined": None if args.sync_steps else enum_ms / args.steps,
-                # the same fraction with the whole step in the denominator (pre-pass, locate,
-                # records and every gap included)
-                "step_frac": cand_rank * OPS_PER_CANDIDATE * args.steps / elapsed / PEAK_INT32_LANE_OPS,
-                "hbm_bytes_algorithmic": slab_bytes,
-                "hbm_frac": slab_bytes / kern_s / 8.0e12,
-                "note": "2 lane-ops (add + max) per candidate x candidates per step / HIP-event time of the "
-                        "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
-                        "their stream, measured on steps launched one at a time after the timed region "
-                        "(inside it two launches share the GPU: kernel_ms_pipelined); the kernel reads 4 bytes "
-                        "of slab per (offset, position) against L2/2 candidates each (hbm_frac of the 8 TB/s "
-                        "peak), so 32-bit VALU issue bounds it, not HBM or MFMA",
-            }
+        if w["stages"] & psa_amd.STAGE_ENUMERATE and w["enum_ms"] > 0:
+            out["roofline"] = roofline_block(args.config, w)
+        if scale is not None:
+            out["scale"] = scale
+        if not args.no_host_inclusive and args.config in ("c1", "c2"):
+            out["host_inclusive"] = host_inclusive(ctx, w["seq1"], w["my_seq2"])
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(seq1, seq2s[0])
+            out["cpu_baseline"] = cpu_baseline(w["seq1"], w["my_seq2"][0])
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if job.dist is not None:
+        job.dist.barrier()
+        job.dist.destroy_process_group()
+    ctx.close()
+    if not parity:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

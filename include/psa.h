@@ -18,6 +18,7 @@
 #ifndef PSA_H
 #define PSA_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -35,8 +36,10 @@ typedef enum psa_status {
   PSA_ERR_RESIDUE = 4,    /* a character outside 'A'..'Z' (the reference indexes out of bounds, P/cudaFunctions.cu:218) */
   PSA_ERR_HIP = 5,        /* a HIP runtime call failed; psa_last_error_text() has the message */
   PSA_ERR_NO_DEVICE = 6,  /* no usable GPU */
-  PSA_ERR_STATE = 7,      /* Seq1 or the table has not been set on the context */
-  PSA_ERR_NOMEM = 8
+  PSA_ERR_STATE = 7,      /* call out of order: Seq1 or the table not set, Seq1 or the table replaced while the
+                             context has batches, a batch used after its context was shut down, wait without enqueue */
+  PSA_ERR_NOMEM = 8,
+  PSA_ERR_COMM = 9        /* the caller's all-gather callback reported a failure */
 } psa_status;
 
 /* stages of one run; 0 means both */
@@ -79,8 +82,20 @@ typedef struct psa_batch psa_batch; /* a set of Seq2 resident in HBM, plus work 
  * Replaces the implicit device 0 and the per-call cudaMalloc/cudaMemcpy of Seq1
  * and the table in calc_best_score_CUDA (P/cudaFunctions.cu:273-288). */
 int psa_device_count(void);
+/* The GPU a process started by a launcher should use: PSA_DEVICE if set, else the process's rank
+ * on its node as the launcher exports it (OMPI_COMM_WORLD_LOCAL_RANK, MV2_COMM_WORLD_LOCAL_RANK,
+ * MPI_LOCALRANKID, PMI_LOCAL_RANK, SLURM_LOCALID, LOCAL_RANK) modulo psa_device_count(), else 0.
+ * The reference never selects a device: both of its ranks use device 0 of their own host
+ * (P/cudaFunctions.cu:260-323, P/myHosts). */
+int psa_default_device(void);
 int psa_init(int device, psa_ctx **out);
+/* Batches of the context that are still alive are detached: their runs are awaited and their
+ * buffers released; afterwards only psa_batch_destroy may be called on them.  A context and its
+ * batches are used by one thread at a time. */
 void psa_shutdown(psa_ctx *ctx);
+/* psa_set_seq1 / psa_set_weights / psa_set_table return PSA_ERR_STATE while the context has
+ * batches: a batch is laid out for the Seq1 and the table it was created under.  Destroy the
+ * batches first. */
 int psa_set_seq1(psa_ctx *ctx, const char *seq1, int64_t len1);
 /* table built from four weights exactly as createCompMatrix does (P/cFunctions.c:55-76) */
 int psa_set_weights(psa_ctx *ctx, const float weights[4]);
@@ -91,7 +106,10 @@ int psa_set_table(psa_ctx *ctx, const float table[PSA_TABLE_SIZE]);
  * Replaces the per-Seq2 loop around calc_best_score_CUDA (P/main.c:79-84, :128-135).
  * len2 may be NULL (then every seq2[i] is NUL-terminated). */
 int psa_batch_create(psa_ctx *ctx, int n, const char *const *seq2, const int32_t *len2, psa_batch **out);
-/* one Seq2 restricted to offsets [s_begin, s_end): the shard of a long pair that one GPU owns */
+/* one Seq2 restricted to offsets [s_begin, s_end): the shard of a long pair that one GPU owns.
+ * The range is clipped to the pair's offsets [0, len1 - len2 + 3); a range that is empty after
+ * clipping (more shards than offsets) yields a valid record without a candidate: status PSA_OK,
+ * n = k = 0, candidates = 0. */
 int psa_batch_create_range(psa_ctx *ctx, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end,
                            psa_batch **out);
 /* launches the kernels on data already resident in HBM and waits for them */
@@ -125,12 +143,35 @@ int psa_score_range(psa_ctx *ctx, const char *seq2, int32_t len2, int64_t s_begi
  * caller's (one all-gather of sizeof(psa_result) bytes per rank). */
 int psa_combine_results(const psa_result *parts, int nparts, psa_result *out);
 
+/* All-gather supplied by the caller: every rank contributes `bytes` bytes at `send` and receives
+ * the contributions of all ranks, in rank order, at `recv` (nranks * bytes); both are host
+ * memory.  Returns 0 on success.  One line around MPI_Allgather or ncclAllGather. */
+typedef int (*psa_allgather_fn)(const void *send, void *recv, size_t bytes, void *comm);
+/* One long pair over nranks ranks, one GPU each, collective included: cuts the pair's offsets
+ * [0, len1 - len2 + 3) into nranks contiguous shards, scores shard `rank` on this context's GPU,
+ * exchanges one sizeof(psa_result)-byte record per rank through `allgather(.., comm)` and
+ * combines them (psa_combine_results), so every rank returns the same record -- the answer
+ * calc_best_score_CUDA would give for the whole pair (P/myProto.h:20; called per Seq2 at
+ * P/main.c:81, :130).  Every rank of the communicator must call it; with nranks == 1 the
+ * callback may be NULL.  A rank whose scoring fails still takes part in the all-gather and all
+ * ranks return that status. */
+int psa_score_range_allgather(psa_ctx *ctx, const char *seq2, int32_t len2, int rank, int nranks,
+                              psa_allgather_fn allgather, void *comm, uint32_t stages, psa_result *out);
+/* The same on a resident batch: `shard` was made by psa_batch_create_range for this rank's offsets
+ * (shard r of nranks owns [S*r/nranks, S*(r+1)/nranks), S = len1 - len2 + 3); one run, one
+ * all-gather, the combine.  For callers that score the same pair repeatedly or keep their shard
+ * in HBM. */
+int psa_batch_run_allgather(psa_batch *shard, int nranks, psa_allgather_fn allgather, void *comm,
+                            uint32_t stages, psa_result *out);
+
 /* ---- the reference's host helpers ------------------------------------------------ */
 /* drop-in for  char* calc_best_score_CUDA(char*, char*, float*)  (P/myProto.h:20,
  * P/cudaFunctions.cu:260-323): returns the malloc'd line
  * "mutant num: %d, MS(%d,%d), score: %1.2f, offset: %d\n" (caller frees, P/main.c:83),
  * echoes it on stdout (P/cudaFunctions.cu:321; PSA_SHIM_QUIET=1 silences it), and on
- * any failure prints to stderr and exits like the reference's macros (P/cudaFunctions.cu:5-18). */
+ * any failure prints to stderr and exits like the reference's macros (P/cudaFunctions.cu:5-18).
+ * Keeps one context per process on GPU psa_default_device() (so the ranks that mpiexec starts
+ * on one node take different GPUs); calls from several threads are serialised. */
 char *psa_calc_best_score(const char *seq1, const char *seq2, const float *comp_matrix);
 /* createCompMatrix (P/cFunctions.c:55-64); size must be PSA_TABLE_SIZE */
 void psa_create_comp_matrix(float *arr, int size, const float *weights);
@@ -142,9 +183,16 @@ void psa_get_nk(int64_t mutant_number, int len2, int *n, int *k);
 int64_t psa_mutant_number(int n, int k, int len2);
 /* the line calcBestScoreOmp formats (P/cFunctions.c:157); malloc'd, caller frees */
 char *psa_format_result(const psa_result *r);
-/* work split replacing calcPortion (P/cFunctions.c:49-52): assigns each Seq2 to one of
- * nparts workers balancing the candidate counts; owner[i] in [0, nparts) */
+/* work split replacing calcPortion (P/cFunctions.c:49-52): assigns each Seq2 to one of nparts
+ * workers (owner[i] in [0, nparts)), largest first onto the least loaded, balancing the predicted
+ * GPU time of the stages that will run (0 = both): with the enumeration stage a model of the
+ * candidate loop, whose candidates per cycle rise with the Seq2 length (0.67 of the peak rate at
+ * 512 characters, 0.84 at 2000), not the raw candidate count; with the resolve stage alone
+ * offsets x length.  psa_partition is psa_partition_stages with stages = 0. */
 int psa_partition(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner);
+int psa_partition_stages(int n, const int32_t *len2, int64_t len1, int nparts, uint32_t stages, int32_t *owner);
+/* the cost that split balances, for one Seq2 (cycles of one SIMD; 0 for an invalid length) */
+double psa_cost_estimate(int32_t len2, int64_t len1, uint32_t stages);
 /* the reference's own split (first n/2 to worker 0, rest to worker 1) for comparison */
 void psa_calc_portion(int *portion, int num);
 

@@ -2,10 +2,13 @@
 // Citations: P/ = "Parallel Solution/", S/ = "Sequential Solution/".
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -87,6 +90,10 @@ struct psa_ctx {
   float *d_table_t = nullptr;          // [27][32] floats, [seq2 code][seq1 code]
   unsigned char *d_class_t = nullptr;  // [27][32] class digits
   std::vector<Bundle *> spare;         // bundles of destroyed batches
+  // Batches created on this context and not yet destroyed.  A batch keeps values derived from
+  // Seq1 and the table (offset ranges, forward blocks, the fixed-point scale), so neither may be
+  // replaced while one exists; psa_shutdown detaches the ones a caller left behind.
+  std::vector<psa_batch *> live;
 };
 
 struct psa_batch {
@@ -183,6 +190,9 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP_C(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PSA_ENUM_I32")) c->enum_f32 = std::atoi(e) == 0;
+  // dynamic-LDS limits of the kernels: an attribute of (kernel, device), so set per context
+  PSA_HIP_C(psa::set_enum_kernel_attributes());
+  PSA_HIP_C(psa::set_resolve_kernel_attributes());
   // Every stream has the same priority.  (With the short kernels' streams at a higher priority
   // than the candidate loop's, a stream that waited for a candidate loop not yet dispatched hung
   // the run: measured.)  The short kernels find room beside the candidate loops because those
@@ -208,6 +218,18 @@ int psa_init(int device, psa_ctx **out) {
 void psa_shutdown(psa_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // Batches the caller has not destroyed: their runs are awaited, their buffers released, and the
+  // handles stay valid for psa_batch_destroy only (every other call on them returns PSA_ERR_STATE).
+  if (!c->live.empty()) {
+    (void)hipDeviceSynchronize();
+    for (psa_batch *b : c->live) {
+      bundle_free(b->res);
+      b->res = nullptr;
+      b->ctx = nullptr;
+      b->pending = b->ran = false;
+    }
+    c->live.clear();
+  }
   if (c->d_seq1) (void)hipFree(c->d_seq1);
   if (c->d_table_t) (void)hipFree(c->d_table_t);
   if (c->d_class_t) (void)hipFree(c->d_class_t);
@@ -227,6 +249,10 @@ int psa_set_seq1(psa_ctx *c, const char *seq1, int64_t len1) {
   if (!c || !seq1) return PSA_ERR_ARG;
   if (len1 < 0) len1 = (int64_t)std::strlen(seq1);
   if (len1 < 1 || len1 > 0x7fff0000ll) return PSA_ERR_ARG;
+  if (!c->live.empty()) {
+    g_err = "psa_set_seq1: the context still has batches (they were laid out for the current Seq1)";
+    return PSA_ERR_STATE;
+  }
   std::vector<unsigned char> codes((size_t)len1);
   for (int64_t i = 0; i < len1; ++i) {
     unsigned char ch = (unsigned char)seq1[i];
@@ -248,6 +274,10 @@ int psa_set_seq1(psa_ctx *c, const char *seq1, int64_t len1) {
 
 int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
   if (!c || !table) return PSA_ERR_ARG;
+  if (!c->live.empty()) {
+    g_err = "psa_set_table: the context still has batches (their fixed-point scale follows the current table)";
+    return PSA_ERR_STATE;
+  }
   std::memcpy(c->table, table, sizeof c->table);
   // device copy: transposed to [seq2 code][seq1 code], zero row and column for the padding code
   std::vector<float> t(psa::kDevTable, 0.0f);
@@ -270,6 +300,8 @@ int psa_set_weights(psa_ctx *c, const float weights[4]) {
 void psa_batch_destroy(psa_batch *b) {
   if (!b) return;
   if (b->ctx) {
+    std::vector<psa_batch *> &live = b->ctx->live;
+    live.erase(std::remove(live.begin(), live.end(), b), live.end());
     (void)hipSetDevice(b->ctx->device);
     if (b->pending) (void)hipDeviceSynchronize();  // a run nobody waited for
     for (int i = 0; i < 2; ++i)
@@ -299,6 +331,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   psa_batch *b = new (std::nothrow) psa_batch();
   if (!b) return PSA_ERR_NOMEM;
   b->ctx = c;
+  c->live.push_back(b);
   b->n = n;
   b->desc.resize((size_t)n);
   b->tmpl.assign((size_t)n, psa_result{});
@@ -340,7 +373,9 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       sb = std::max<int64_t>(rb, 0);
       se = std::min<int64_t>(re, S);
       if (se <= sb) {
-        r.status = PSA_ERR_ARG;
+        // a shard that owns no offset (more shards than offsets): a valid record without a
+        // candidate (n = 0, candidates = 0), which psa_combine_results passes over
+        r.status = PSA_OK;
         continue;
       }
     }
@@ -801,6 +836,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
 
 int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
   if (!b) return PSA_ERR_ARG;
+  if (!b->ctx) return PSA_ERR_STATE;  // its context was shut down
   if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   psa_ctx *c = b->ctx;
   b->ran = false;
@@ -826,7 +862,7 @@ int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
 
 int psa_batch_wait(psa_batch *b) {
   if (!b) return PSA_ERR_ARG;
-  if (!b->pending) return PSA_ERR_STATE;
+  if (!b->ctx || !b->pending) return PSA_ERR_STATE;
   b->pending = false;
   if (b->n == 0) {
     b->ran = true;
@@ -837,6 +873,12 @@ int psa_batch_wait(psa_batch *b) {
   // the record kernels are the last of their streams
   if (b->pending_timed) PSA_HIP(hipEventSynchronize(b->ev_last));
   if (b->pending_resolve) PSA_HIP(hipEventSynchronize(b->ev_res));
+  // The run enqueued before the last one ends on the other candidate-loop stream (locate and its
+  // record kernel) and nothing orders it before the last run's tail: wait for it too, so that
+  // after this call no kernel of the batch is in flight (psa_batch_destroy then hands the
+  // buffers to the next batch without synchronising).
+  for (int i = 0; i < 2; ++i)
+    if (b->tail_recorded[i]) PSA_HIP(hipEventSynchronize(b->ev_tail[i]));
   b->upload_in_flight = false;
   b->enum_ms = 0.f;
   b->total_ms = 0.f;
@@ -876,7 +918,7 @@ int psa_batch_run(psa_batch *b, uint32_t stages) {
 
 int psa_batch_results(const psa_batch *b, psa_result *out) {
   if (!b || (!out && b->n > 0)) return PSA_ERR_ARG;
-  if (!b->ran) return PSA_ERR_STATE;
+  if (!b->ctx || !b->ran) return PSA_ERR_STATE;
   if (b->n > 0) std::memcpy(out, b->h_out, (size_t)b->n * sizeof(psa_result));
   return PSA_OK;
 }
@@ -910,10 +952,91 @@ int psa_score_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s_begin,
   return st;
 }
 
+// ---- one long pair over several ranks ----------------------------------------------
+// The reference has no such mode (it calls calc_best_score_CUDA once per Seq2, P/main.c:81,
+// :130, and each call walks all offsets); here the offsets [0, S) of one pair are cut into
+// nranks contiguous shards, this rank scores its shard on its GPU, the caller's all-gather
+// moves one record per rank, and every rank combines them to the same answer.
+// A resident one-Seq2 batch (this rank's offset shard) run once, then the exchange and combine.
+int psa_batch_run_allgather(psa_batch *b, int nranks, psa_allgather_fn allgather, void *comm, uint32_t stages,
+                            psa_result *out) {
+  if (!b || !out || nranks < 1 || (nranks > 1 && !allgather)) return PSA_ERR_ARG;
+  if (!b->ctx) return PSA_ERR_STATE;
+  if (b->n != 1) {
+    g_err = "psa_batch_run_allgather: the batch must hold exactly one Seq2 (one shard of one pair)";
+    return PSA_ERR_ARG;
+  }
+  psa_result mine{};
+  int st = psa_batch_run(b, stages);
+  if (st == PSA_OK) st = psa_batch_results(b, &mine);
+  // A rank whose run failed still takes part in the collective (the others are already waiting
+  // in it) and reports the failure through its record.
+  if (st != PSA_OK) {
+    mine = psa_result{};
+    mine.status = st;
+  }
+  if (nranks == 1) {  // what the combine returns for one part
+    *out = mine;
+    return st != PSA_OK ? st : mine.status;
+  }
+  std::vector<psa_result> parts((size_t)nranks);
+  if (allgather(&mine, parts.data(), sizeof(psa_result), comm) != 0) {
+    g_err = "psa_batch_run_allgather: the caller's all-gather reported a failure";
+    return PSA_ERR_COMM;
+  }
+  return psa_combine_results(parts.data(), nranks, out);
+}
+
+int psa_score_range_allgather(psa_ctx *c, const char *seq2, int32_t len2, int rank, int nranks,
+                              psa_allgather_fn allgather, void *comm, uint32_t stages, psa_result *out) {
+  if (!c || !seq2 || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !allgather))
+    return PSA_ERR_ARG;
+  if (!c->have_seq1 || !c->have_table) return PSA_ERR_STATE;
+  const int64_t L2 = len2 >= 0 ? (int64_t)len2 : (int64_t)std::strlen(seq2);
+  const int64_t S = c->len1 - L2 + 3;  // P/cudaFunctions.cu:269
+  // (an invalid pair is invalid for every rank alike: any range lets the batch record the status)
+  const int64_t lo = S >= 1 ? S * rank / nranks : 0, hi = S >= 1 ? S * (rank + 1) / nranks : 1;
+  psa_batch *b = nullptr;
+  int st = psa_batch_create_range(c, seq2, len2, lo, hi, &b);
+  if (st != PSA_OK) {
+    // still enter the collective, so that the other ranks do not wait for this one forever
+    psa_result mine{};
+    mine.status = st;
+    std::vector<psa_result> parts((size_t)nranks);
+    if (nranks > 1) (void)allgather(&mine, parts.data(), sizeof(psa_result), comm);
+    return st;
+  }
+  st = psa_batch_run_allgather(b, nranks, allgather, comm, stages, out);
+  psa_batch_destroy(b);
+  return st;
+}
+
+// ---- which GPU a process started by a launcher should use ----------------------------
+// PSA_DEVICE if set; otherwise this process's rank on its node as the launcher exports it
+// (Open MPI, MVAPICH2, MPICH/Intel MPI hydra, PMI, Slurm, torch.distributed.run), modulo the
+// number of visible GPUs; otherwise 0.  The reference never calls cudaSetDevice: each of its
+// two ranks uses device 0 of its own host (P/cudaFunctions.cu:260-323, P/myHosts).
+int psa_default_device(void) {
+  const int ngpu = psa_device_count();
+  if (const char *e = std::getenv("PSA_DEVICE")) return std::atoi(e);
+  static const char *const kLocalRankVars[] = {"OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK",
+                                               "MPI_LOCALRANKID", "PMI_LOCAL_RANK", "SLURM_LOCALID", "LOCAL_RANK"};
+  for (const char *name : kLocalRankVars)
+    if (const char *e = std::getenv(name)) {
+      char *end = nullptr;
+      const long v = std::strtol(e, &end, 10);
+      if (end != e && v >= 0) return ngpu > 0 ? (int)(v % ngpu) : 0;
+    }
+  return 0;
+}
+
 // ---- drop-in for calc_best_score_CUDA (P/cudaFunctions.cu:260-323) ----------------
 // Keeps one context alive; Seq1 and the table are uploaded again only when they
 // change between calls (the reference re-uploads both for every Seq2 and never frees).
 char *psa_calc_best_score(const char *seq1, const char *seq2, const float *comp_matrix) {
+  // One context per process, shared by every caller: calls are serialised (the reference calls
+  // from one thread per rank, P/main.c:79-84).
+  static std::mutex mu;
   static psa_ctx *ctx = nullptr;
   static std::string cached_seq1;
   static float cached_table[PSA_TABLE_SIZE];
@@ -923,10 +1046,14 @@ char *psa_calc_best_score(const char *seq1, const char *seq2, const float *comp_
     std::exit(EXIT_FAILURE);
   };
   if (!seq1 || !seq2 || !comp_matrix) die("psa_calc_best_score", PSA_ERR_ARG);
+  std::lock_guard<std::mutex> lock(mu);
   int st;
   if (!ctx) {
-    const char *dev = std::getenv("PSA_DEVICE");
-    if ((st = psa_init(dev ? std::atoi(dev) : 0, &ctx)) != PSA_OK) die("psa_init", st);
+    const int dev = psa_default_device();
+    if (std::getenv("PSA_DEBUG_SYNC"))
+      std::fprintf(stderr, "[psa] psa_calc_best_score: pid %d uses GPU %d of %d\n", (int)getpid(), dev,
+                   psa_device_count());
+    if ((st = psa_init(dev, &ctx)) != PSA_OK) die("psa_init", st);
   }
   if (cached_seq1 != seq1) {
     if ((st = psa_set_seq1(ctx, seq1, -1)) != PSA_OK) die("psa_set_seq1", st);

@@ -595,28 +595,35 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair: it is set for
+// every kernel variant on the device that is current, once per context (set_enum_kernel_attributes,
+// called by psa_init), not remembered in a process-wide flag.
 template <int NT, int R>
 static hipError_t set_lds_attr() {
   using L = EnumLds<NT, R>;
-  static bool attr_done = false;
-  if (attr_done) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           L::total);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)psa_enum_locate<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-  if (e != hipSuccess) return e;
-  attr_done = true;
-  return hipSuccess;
+  return hipFuncSetAttribute((const void *)psa_enum_locate<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+}
+
+hipError_t set_enum_kernel_attributes() {
+  hipError_t e;
+  if ((e = set_lds_attr<256, 1>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<256, 2>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<512, 2>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<512, 4>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1024, 4>()) != hipSuccess) return e;
+  return set_lds_attr<1024, 8>();
 }
 
 template <int NT, int R>
 static hipError_t launch_prep_t(const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
                                 hipEvent_t ev_stop) {
-  hipError_t e = set_lds_attr<NT, R>();
-  if (e != hipSuccess) return e;
+  hipError_t e;
   if (f32)
     hipExtLaunchKernelGGL((psa_enum_prep<NT, R, true>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st,
                           ev_start, ev_stop, 0, P);
@@ -629,8 +636,7 @@ static hipError_t launch_prep_t(const EnumParams &P, bool f32, hipStream_t st, h
 
 template <int NT, int R>
 static hipError_t launch_locate_t(const EnumParams &P, int grid, hipStream_t st) {
-  hipError_t e = set_lds_attr<NT, R>();
-  if (e != hipSuccess) return e;
+  hipError_t e;
   hipLaunchKernelGGL((psa_enum_locate<NT, R>), dim3(grid), dim3(NT), (EnumLds<NT, R>::total), st, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_enum_locate");

@@ -131,16 +131,40 @@ void nk_of_mutant(int64_t t, int len2, int *n, int *k) {
 
 int64_t mutant_of_nk(int n, int k, int len2) { return row_start(n, len2) + (k - n) - 1; }
 
-// Longest-processing-time assignment on the candidate count of each Seq2.
-int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner) {
+// Predicted cost of one Seq2, in cycles of one SIMD.
+//
+// Enumeration stage: the candidate loop scores 64 candidates (one q against one register of 64
+// positions p) in 4 cycles at the peak issue rate; measured on MI355X it needs about 4.3 in the
+// long phase (vector operands), 4.6 for the full blocks inside a level's own 256 positions (scalar
+// operands), 6 along the diagonal (half of those candidates do not exist), and about 580 cycles
+// per (offset, level) for the scalar and per-lane loads and their waits.  Candidates per cycle
+// therefore fall with the Seq2 length: 0.67 of the peak at 512 characters, 0.84 at 2000, 0.95 at
+// 8000 -- a split by raw candidate counts gives the rank with the short Seq2 more time than work.
+// Resolve stage alone: one dependent float32 chain step per (offset, position).
+double cost_estimate(int64_t len2, int64_t len1, uint32_t stages) {
+  const int64_t S = len1 - len2 + 3;
+  if (S <= 0 || len2 < 2) return 0.0;
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  if (!(stages & PSA_STAGE_ENUMERATE)) return double(S) * double(len2);
+  const int64_t nruns = (len2 + 63) / 64, qlast = (len2 + 15) & ~int64_t(15);
+  double cyc = 0.0;
+  for (int64_t pc0 = 0; pc0 < nruns; pc0 += 4) {
+    const int64_t long_q = std::max<int64_t>(0, qlast - 64 * (pc0 + 4));
+    const int64_t present = std::min<int64_t>(4, nruns - pc0);
+    cyc += 4.3 * 4.0 * double(long_q);                                                  // long phase, 4 registers
+    cyc += 4.6 * 64.0 * double(present * (present - 1) / 2) + 6.0 * 64.0 * double(present);  // own block
+    cyc += 580.0 * double(present) / 4.0;
+  }
+  return double(S) * cyc;
+}
+
+// Longest-processing-time assignment on the predicted cost of each Seq2.
+int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, uint32_t stages, int32_t *owner) {
   if (n < 0 || nparts < 1 || (n > 0 && (!len2 || !owner))) return PSA_ERR_ARG;
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
   std::vector<double> cost(n);
-  for (int i = 0; i < n; ++i) {
-    double L2 = len2[i], S = double(len1) - L2 + 3.0;
-    cost[i] = S > 0 && L2 >= 2 ? S * L2 * (L2 - 1.0) * 0.5 : 0.0;
-  }
+  for (int i = 0; i < n; ++i) cost[i] = cost_estimate(len2[i], len1, stages);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
   std::vector<double> load(nparts, 0.0);
   for (int idx : order) {
@@ -184,8 +208,14 @@ char *psa_format_result(const psa_result *r) {
 }
 
 int psa_partition(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner) {
-  return psa::partition_by_cost(n, len2, len1, nparts, owner);
+  return psa::partition_by_cost(n, len2, len1, nparts, 0u, owner);
 }
+
+int psa_partition_stages(int n, const int32_t *len2, int64_t len1, int nparts, uint32_t stages, int32_t *owner) {
+  return psa::partition_by_cost(n, len2, len1, nparts, stages, owner);
+}
+
+double psa_cost_estimate(int32_t len2, int64_t len1, uint32_t stages) { return psa::cost_estimate(len2, len1, stages); }
 
 void psa_calc_portion(int *portion, int num) {
   // P/cFunctions.c:49-52: floor(num/2) for the first worker, the rest for the second
@@ -203,13 +233,14 @@ const char *psa_strerror(int status) {
     case PSA_ERR_RESIDUE: return "character outside 'A'..'Z'";
     case PSA_ERR_HIP: return "HIP runtime error";
     case PSA_ERR_NO_DEVICE: return "no usable GPU";
-    case PSA_ERR_STATE: return "Seq1 or table not set";
+    case PSA_ERR_STATE: return "call out of order (Seq1 or table not set, or replaced under live batches; batch without context; wait without enqueue)";
     case PSA_ERR_NOMEM: return "out of memory";
+    case PSA_ERR_COMM: return "the caller's all-gather failed";
     default: return "unknown status";
   }
 }
 
-const char *psa_version(void) { return "psa-hip 0.1 (gfx950)"; }
+const char *psa_version(void) { return "psa-hip 0.2 (gfx950)"; }
 
 int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
   if (!parts || !out || nparts < 1) return PSA_ERR_ARG;

@@ -66,7 +66,8 @@ constexpr int kSumBitsF32 = 23;  // and in float32 arithmetic (integers of at mo
 int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int sum_bits, int *exact_level);
 void nk_of_mutant(int64_t t, int len2, int *n, int *k);
 int64_t mutant_of_nk(int n, int k, int len2);
-int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner);
+double cost_estimate(int64_t len2, int64_t len1, uint32_t stages);
+int partition_by_cost(int n, const int32_t *len2, int64_t len1, int nparts, uint32_t stages, int32_t *owner);
 
 }  // namespace psa
 

@@ -74,6 +74,9 @@ int enum_class_lds_bytes(int c);
 int enum_class_threads(int c);
 
 hipError_t debug_sync(const char *what);
+// dynamic-LDS limits of every kernel variant on the current device (per device, so per context)
+hipError_t set_enum_kernel_attributes();
+hipError_t set_resolve_kernel_attributes();
 hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hipStream_t st);
 // ev_start / ev_stop (may be null) are attached to the kernel's dispatch, not recorded beside it
 // f32: the slab holds float32 values and the candidate loop adds and compares in float32

@@ -582,21 +582,24 @@ static size_t tie_lds(int max_len2) {
   return (size_t)kDevTable * 4 + 4 * (size_t)tie_d0_len(max_len2) + 8 * (size_t)tie_d12_len(max_len2);
 }
 
+// The dynamic-LDS limits of the resolve kernels for the device that is current: once per context
+// (psa_init), sized for the longest Seq2 the library takes.  The attribute belongs to the
+// (kernel, device) pair, so nothing about it is remembered process-wide.
+hipError_t set_resolve_kernel_attributes() {
+  hipError_t e;
+  const int tb = (int)tie_lds(PSA_MAX_SEQ2);
+  e = hipFuncSetAttribute((const void *)psa_first_p, hipFuncAttributeMaxDynamicSharedMemorySize, tb);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)psa_first_q, hipFuncAttributeMaxDynamicSharedMemorySize, tb);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)psa_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)fwd_lds(PSA_MAX_SEQ2));
+}
+
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,
                           hipEvent_t ev_start) {
-  static size_t attr_bytes = 0;
   hipError_t e;
   const size_t tb = tie_lds(max_len2);
-  if (tb > attr_bytes) {
-    e = hipFuncSetAttribute((const void *)psa_first_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)psa_first_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)psa_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)fwd_lds(PSA_MAX_SEQ2));
-    if (e != hipSuccess) return e;
-    attr_bytes = tb;
-  }
   hipExtLaunchKernelGGL(psa_fwd, dim3(nfwd_blocks), dim3(256), fwd_lds(max_len2), st, ev_start, nullptr, 0, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = debug_sync("psa_fwd")) != hipSuccess) return e;

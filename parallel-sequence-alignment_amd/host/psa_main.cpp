@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
   const int n = (int)seq2.size();
   std::vector<int32_t> len2((size_t)n), owner((size_t)n, 0);
   for (int i = 0; i < n; ++i) len2[(size_t)i] = (int32_t)seq2[(size_t)i].size();
-  psa_partition(n, len2.data(), (int64_t)seq1.size(), ngpu, owner.data());
+  psa_partition_stages(n, len2.data(), (int64_t)seq1.size(), ngpu, PSA_STAGE_RESOLVE, owner.data());
 
   std::vector<psa_result> results((size_t)n);
   std::vector<int> worker_status((size_t)ngpu, PSA_OK);

@@ -6,14 +6,18 @@
 // and rank 0 writes one line per Seq2 in input order to "output.txt" and echoes it
 // (P/main.c:79-94).  What changes: the reference is fixed to two ranks (P/main.c:20-24) and
 // splits by count (P/cFunctions.c:49-52, rank 0 takes the first half); here the split
-// balances the candidate counts over all ranks (psa_partition), the sequences travel as one
+// balances the predicted GPU time over all ranks (psa_partition_stages), the sequences travel as one
 // broadcast instead of one MPI_Send per Seq2, and the answers come back as fixed-size
 // records (one MPI_Gatherv) instead of formatted lines.  Buffers are dynamic.
 //
-//   mpiexec -np N psa_mpi [--dry-run] [input.txt [output.txt]]
+//   mpiexec -np N psa_mpi [--dry-run] [--long-pair] [input.txt [output.txt]]
 //
 // A rank uses GPU (rank on its node) mod (GPUs of the node).  --dry-run does everything but
 // the scoring and prints which rank owns which Seq2: a check of the plumbing without a GPU.
+// --long-pair scores every Seq2 on all ranks together instead of giving each Seq2 to one rank:
+// the offsets of the pair are cut into one contiguous shard per rank, and one MPI_Allgather of
+// one record per rank inside psa_score_range_allgather brings the shards' answers together (for
+// a Seq1 so long that one pair is the whole job; the output is the same).
 #include <mpi.h>
 
 #include <chrono>
@@ -24,6 +28,11 @@
 #include <vector>
 
 #include "psa.h"
+
+// the all-gather psa_score_range_allgather calls: comm points to the MPI communicator
+static int mpi_allgather(const void *send, void *recv, size_t bytes, void *comm) {
+  return MPI_Allgather(send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, *(MPI_Comm *)comm) == MPI_SUCCESS ? 0 : 1;
+}
 
 static bool read_token(FILE *f, std::string &tok) {
   tok.clear();
@@ -41,11 +50,13 @@ int main(int argc, char **argv) {
   int rank = 0, size = 1;
   MPI_Comm_rank(MPI_COMM_WORLD, &rank);
   MPI_Comm_size(MPI_COMM_WORLD, &size);
-  bool dry = false;
+  bool dry = false, long_pair = false;
   std::vector<const char *> pos;
   for (int i = 1; i < argc; ++i) {
     if (std::strcmp(argv[i], "--dry-run") == 0)
       dry = true;
+    else if (std::strcmp(argv[i], "--long-pair") == 0)
+      long_pair = true;
     else
       pos.push_back(argv[i]);
   }
@@ -113,9 +124,59 @@ int main(int argc, char **argv) {
   }
   seq1.assign(blob.data(), (size_t)header[0]);
 
+  int local = 0;  // my place among the ranks of this node (a collective: every rank takes part)
+  {
+    MPI_Comm node;
+    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
+    MPI_Comm_rank(node, &local);
+    MPI_Comm_free(&node);
+  }
+
+  if (long_pair && !dry) {
+    // every Seq2 is scored by all ranks together, offsets sharded, one all-gather per Seq2
+    const int ngpu = psa_device_count();
+    psa_ctx *ctx = nullptr;
+    int st = ngpu > 0 ? psa_init(local % ngpu, &ctx) : PSA_ERR_NO_DEVICE;
+    if (st == PSA_OK) st = psa_set_seq1(ctx, seq1.c_str(), (int64_t)seq1.size());
+    if (st == PSA_OK) st = psa_set_weights(ctx, weights);
+    int worst = st;
+    MPI_Allreduce(&st, &worst, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);  // nobody enters the all-gathers alone
+    if (st != PSA_OK)
+      std::fprintf(stderr, "psa_mpi: rank %d: %s (%s)\n", rank, psa_strerror(st), psa_last_error_text());
+    int rc = worst == PSA_OK ? 0 : EXIT_FAILURE;
+    MPI_Comm world = MPI_COMM_WORLD;
+    size_t at = (size_t)header[0];
+    for (int i = 0; i < n && rc == 0; ++i) {
+      psa_result res;
+      st = psa_score_range_allgather(ctx, blob.data() + at, len2[(size_t)i], rank, size, mpi_allgather, &world,
+                                     PSA_STAGE_RESOLVE, &res);
+      at += (size_t)len2[(size_t)i];
+      if (st != PSA_OK || res.status != PSA_OK) {  // the same on every rank: the records were all-gathered
+        if (rank == 0)
+          std::fprintf(stderr, "psa_mpi: Seq2 #%d: %s\n", i + 1, psa_strerror(st != PSA_OK ? st : res.status));
+        rc = EXIT_FAILURE;
+        break;
+      }
+      if (rank == 0) {
+        char *line = psa_format_result(&res);
+        std::printf("%s", line);
+        std::fprintf(out, "%s", line);  // P/cFunctions.c:45
+        std::free(line);
+      }
+    }
+    psa_shutdown(ctx);
+    if (rank == 0) {
+      if (out) std::fclose(out);
+      double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+      std::printf("Total Time: %1.4f\n", secs);  // P/main.c:97
+    }
+    MPI_Finalize();
+    return rc;
+  }
+
   // every rank computes the same split
   std::vector<int32_t> owner((size_t)n, 0);
-  psa_partition(n, len2.data(), (int64_t)seq1.size(), size, owner.data());
+  psa_partition_stages(n, len2.data(), (int64_t)seq1.size(), size, PSA_STAGE_RESOLVE, owner.data());
   std::vector<std::string> mine_s;
   std::vector<int> mine_idx;
   {
@@ -133,13 +194,6 @@ int main(int argc, char **argv) {
   // score my share on the GPU that goes with my place on this node
   std::vector<psa_result> mine_r(mine_s.size());
   int st = PSA_OK;
-  int local = 0;  // my place among the ranks of this node (a collective: every rank takes part)
-  {
-    MPI_Comm node;
-    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
-    MPI_Comm_rank(node, &local);
-    MPI_Comm_free(&node);
-  }
   if (!dry && !mine_s.empty()) {
     const int ngpu = psa_device_count();
     psa_ctx *ctx = nullptr;

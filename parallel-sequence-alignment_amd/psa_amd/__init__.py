@@ -53,6 +53,9 @@ class Result(C.Structure):
         return d
 
 
+# int (*psa_allgather_fn)(const void *send, void *recv, size_t bytes, void *comm)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
 _lib = None
 
 
@@ -67,6 +70,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, f32p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.psa_device_count.restype = C.c_int
+    L.psa_default_device.restype = C.c_int
+    L.psa_score_range_allgather.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int, ALLGATHER_FN, vp,
+                                            C.c_uint32, C.POINTER(Result)]
+    L.psa_batch_run_allgather.argtypes = [vp, C.c_int, ALLGATHER_FN, vp, C.c_uint32, C.POINTER(Result)]
     L.psa_init.argtypes = [C.c_int, C.POINTER(vp)]
     L.psa_shutdown.argtypes = [vp]
     L.psa_shutdown.restype = None
@@ -98,6 +105,9 @@ def lib():
     L.psa_format_result.argtypes = [C.POINTER(Result)]
     L.psa_format_result.restype = C.c_void_p
     L.psa_partition.argtypes = [C.c_int, i32p, C.c_int64, C.c_int, i32p]
+    L.psa_partition_stages.argtypes = [C.c_int, i32p, C.c_int64, C.c_int, C.c_uint32, i32p]
+    L.psa_cost_estimate.argtypes = [C.c_int32, C.c_int64, C.c_uint32]
+    L.psa_cost_estimate.restype = C.c_double
     L.psa_calc_portion.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.psa_calc_portion.restype = None
     L.psa_strerror.argtypes = [C.c_int]
@@ -181,13 +191,23 @@ def calcPortion(num):
     return p[0], p[1]
 
 
-def partition(len2, len1, nparts):
-    """Cost-balanced owner of each Seq2 (replaces the count-based calcPortion)."""
+def partition(len2, len1, nparts, stages=0):
+    """Cost-balanced owner of each Seq2 (replaces the count-based calcPortion); the cost is the
+    predicted GPU time of the stages that will run (0 = both)."""
     l2 = np.ascontiguousarray(len2, dtype=np.int32)
     owner = np.zeros(len(l2), dtype=np.int32)
-    _check(lib().psa_partition(len(l2), l2.ctypes.data_as(C.POINTER(C.c_int32)), len1, nparts,
-                               owner.ctypes.data_as(C.POINTER(C.c_int32))), "psa_partition")
+    _check(lib().psa_partition_stages(len(l2), l2.ctypes.data_as(C.POINTER(C.c_int32)), len1, nparts, stages,
+                                      owner.ctypes.data_as(C.POINTER(C.c_int32))), "psa_partition_stages")
     return owner
+
+
+def cost_estimate(len2, len1, stages=0):
+    return lib().psa_cost_estimate(len2, len1, stages)
+
+
+def default_device():
+    """GPU for this process: PSA_DEVICE, else the launcher's local rank modulo the GPU count, else 0."""
+    return lib().psa_default_device()
 
 
 def calc_best_score(seq1, seq2, comp_matrix):
@@ -210,6 +230,25 @@ def combine_results(parts):
 
 
 # ---- resident-data API -------------------------------------------------------------
+
+def _allgather_callback(allgather, nranks):
+    """Wraps `allgather(send: bytes) -> bytes of all ranks in rank order` as a psa_allgather_fn."""
+    if allgather is None:
+        return ALLGATHER_FN()
+
+    def _cb(send, recv, nbytes, _comm):
+        try:
+            got = allgather(C.string_at(send, nbytes))
+            if len(got) != nbytes * nranks:
+                return 1
+            C.memmove(recv, got, len(got))
+            return 0
+        except Exception:  # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+    return ALLGATHER_FN(_cb)
+
 
 class Context:
     """One per GPU: Seq1 and the table stay in HBM across batches."""
@@ -260,6 +299,17 @@ class Context:
         finally:
             b.close()
 
+    def score_range_allgather(self, seq2, rank, nranks, allgather=None, stages=STAGE_BOTH):
+        """One long pair over nranks ranks (psa_score_range_allgather): this rank's offset shard is
+        scored here, `allgather(send: bytes) -> bytes of all ranks in rank order` moves the records,
+        and every rank returns the combined record."""
+        cb = _allgather_callback(allgather, nranks)
+        b = _bytes(seq2)
+        out = Result()
+        _check(lib().psa_score_range_allgather(self._h, b, len(b), rank, nranks, cb, None, stages, C.byref(out)),
+               "psa_score_range_allgather")
+        return out
+
     def score_range(self, seq2, s_begin, s_end, stages=STAGE_BOTH):
         b = Batch(self, [seq2], (s_begin, s_end))
         try:
@@ -308,6 +358,14 @@ class Batch:
     def run(self, stages=STAGE_BOTH):
         self.launch(stages)
         return self.results()
+
+    def run_allgather(self, nranks, allgather=None, stages=STAGE_BOTH):
+        """A resident shard of one long pair (Context.batch_range): one run, one all-gather of one
+        record per rank, the max-loc combine; every rank returns the same record."""
+        out = Result()
+        _check(lib().psa_batch_run_allgather(self._h, nranks, _allgather_callback(allgather, nranks), None, stages,
+                                             C.byref(out)), "psa_batch_run_allgather")
+        return out
 
     def timing(self):
         """(enumeration kernel ms, first launch to last completion ms) of the last run"""

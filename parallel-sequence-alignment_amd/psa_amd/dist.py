@@ -33,9 +33,9 @@ def _device(group=None):
     return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
 
-def my_share(len2, len1, rank, world):
-    """Indices (ascending) of the Seq2 this rank scores."""
-    owner = partition(len2, len1, world)
+def my_share(len2, len1, rank, world, stages=0):
+    """Indices (ascending) of the Seq2 this rank scores (split balanced for the stages that run)."""
+    owner = partition(len2, len1, world, stages)
     return [i for i in range(len(len2)) if owner[i] == rank], owner
 
 
@@ -80,6 +80,30 @@ def gather_results(local_results, my_indices, n_total, group=None):
             out[i] = Result.from_buffer_copy(bytes(row[:RECORD_BYTES]))
     assert all(o is not None for o in out), "a Seq2 was scored by no rank"
     return out
+
+
+def allgather_bytes(group=None):
+    """The all-gather callback of Context.score_range_allgather over torch.distributed: every rank
+    passes the same number of bytes and gets the concatenation in rank order."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    dev = _device(group)
+
+    def fn(send):
+        mine = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        return bytes(torch.cat(parts).cpu().numpy())
+    return fn
+
+
+def score_long_pair(ctx, seq2, stages=3, group=None):
+    """One long pair on all ranks of the group: offsets sharded, one all-gather of one record per
+    rank inside the library call, the same combined record on every rank."""
+    dist = _dist()
+    return ctx.score_range_allgather(seq2, dist.get_rank(group), dist.get_world_size(group),
+                                     allgather_bytes(group), stages)
 
 
 def combine_shards(local_result, group=None):

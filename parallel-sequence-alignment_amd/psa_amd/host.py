@@ -61,7 +61,7 @@ def run(input_file_name="input.txt", output_file_name="output.txt", scorer=None,
     weights, seq1, seq2s = payload[0]
     weights = np.array(weights, dtype=np.float32)
     len2 = [len(s) for s in seq2s]
-    mine, _ = pdist.my_share(len2, len(seq1), rank, world)
+    mine, _ = pdist.my_share(len2, len(seq1), rank, world, STAGE_RESOLVE)
     local = scorer(seq1, weights, [seq2s[i] for i in mine], local_rank)
     results = pdist.gather_results(local, mine, len(seq2s)) if dist is not None else local
     lines = None

@@ -60,6 +60,11 @@ def main():
         whole = record_from_oracle(seq1, seq2, table)
         checks.append(comb.key() == whole.key() and comb.enum_key() == whole.enum_key()
                       and comb.candidates == whole.candidates)
+        # the all-gather callback that psa_score_range_allgather is given: every rank's bytes, in rank order
+        got = pdist.allgather_bytes()(bytes(mine))
+        parts = pdist.array_to_records(np.frombuffer(got, dtype=np.uint8).reshape(world, pdist.RECORD_BYTES))
+        assert bytes(parts[rank]) == bytes(mine)
+        assert psa_amd.combine_results(parts).key() == whole.key()
     with open(os.path.join(out_dir, "combine_rank%d.txt" % rank), "w") as f:
         f.write(" ".join("ok" if c else "BAD" for c in checks))
     dist.barrier()

@@ -47,6 +47,17 @@ def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=
                 if exact == 2:
                     assert (r.enum_n, r.enum_k, r.enum_offset) == (r.n, r.k, r.offset)
                     assert r.enum_score == float(r.score) * 2.0 ** fr
+                # The enumerated maximum and the float32 answer are the same quantity up to rounding.
+                # For one candidate of m table entries x_i, the float32 left-to-right sum differs from
+                # the exact sum by at most gamma_{m-1} sum|x_i| (gamma_k = k u / (1 - k u), u = 2^-24) and
+                # the fixed-point score times 2^-r by at most m 2^-(r+1) (entries rounded to nearest):
+                # b bounds both together.  Then the two maxima differ by at most b, and the float32
+                # winner's own fixed-point score lies within 2b of the enumerated maximum.
+                m, u = L2 - 2, 2.0 ** -24
+                b = (m - 1) * u / (1 - (m - 1) * u) * m * float(np.abs(table).max()) + m * 2.0 ** -(fr + 1)
+                assert abs(float(r.score) - r.enum_score * 2.0 ** -fr) <= b, ("maxima apart", i, r.score, r.enum_score, fr, b)
+                ef = oracle.enum_score(seq1, seq2, itab, r.offset, r.n, r.k)
+                assert ef <= r.enum_score and (r.enum_score - ef) * 2.0 ** -fr <= 2 * b, ("winner apart", i, ef, r.enum_score)
 
 
 def test_golden_vectors(psa, ctx, oracle, golden):
@@ -328,6 +339,108 @@ def test_offset_range_shards_combine(psa, ctx, oracle):
     assert (comb.n, comb.k, comb.offset) == (1, 2, 0)
 
 
+def test_offset_shards_more_than_offsets(psa, ctx, oracle):
+    """More shards than offsets (Seq2 two characters longer than Seq1: one offset): the shards
+    without an offset return a valid record without a candidate, and the combine passes over them."""
+    from psa_amd import dist as pdist
+    seq1, seq2s = synth_problem(22, 60, [62])
+    seq2 = seq2s[0]
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    whole = ctx.score_batch([seq2])[0]
+    assert whole.status == 0 and whole.candidates == 62 * 61 // 2
+    parts = [ctx.score_range(seq2, *pdist.offset_shard(1, r, 4)) for r in range(4)]
+    assert [p.status for p in parts] == [0, 0, 0, 0]
+    assert sorted(p.candidates for p in parts) == [0, 0, 0, whole.candidates]
+    assert all(p.n == 0 and p.enum_n == 0 for p in parts if p.candidates == 0)
+    comb = psa.combine_results(parts)
+    assert comb.key() == whole.key() and comb.enum_key() == whole.enum_key() and comb.candidates == whole.candidates
+    assert psa.combine_results(parts[:3]).n == 0  # only empty shards: a record without a candidate
+
+
+def test_long_pair_allgather_entry(psa, ctx, oracle):
+    """psa_score_range_allgather / psa_batch_run_allgather: the shard of `rank`, one all-gather through
+    the caller's callback, the combine.  The other ranks are played by the callback, which scores
+    their shards on the same GPU."""
+    from psa_amd import dist as pdist
+    seq1, seq2s = synth_problem(23, 4000, [700])
+    seq2 = seq2s[0]
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    whole = ctx.score_batch([seq2])[0]
+    check_against_oracle(oracle, seq1, [seq2], table, [whole])
+    S = len(seq1) - len(seq2) + 3
+    for nranks in (1, 3):
+        for rank in range(nranks):
+            calls = []
+
+            stages = [psa.STAGE_BOTH]
+
+            def gather(send, rank=rank, nranks=nranks):
+                calls.append(len(send))
+                parts = []
+                for r in range(nranks):
+                    parts.append(send if r == rank else
+                                 bytes(ctx.score_range(seq2, *pdist.offset_shard(S, r, nranks), stages[0])))
+                return b"".join(parts)
+            got = ctx.score_range_allgather(seq2, rank, nranks, gather if nranks > 1 else None)
+            assert (got.key(), got.enum_key(), tuple(got.counts), got.candidates) == \
+                (whole.key(), whole.enum_key(), tuple(whole.counts), whole.candidates)
+            assert calls == ([96] if nranks > 1 else [])
+            b = ctx.batch_range(seq2, *pdist.offset_shard(S, rank, nranks))
+            stages[0] = psa.STAGE_RESOLVE
+            for _ in range(2):  # resident shard, run twice
+                got = b.run_allgather(nranks, gather if nranks > 1 else None, psa.STAGE_RESOLVE)
+                assert got.key() == whole.key() and got.enum_n == 0
+            b.close()
+    # a callback that fails is reported, not swallowed
+    with pytest.raises(psa.PsaError) as ei:
+        ctx.score_range_allgather(seq2, 0, 2, lambda send: b"")
+    assert ei.value.status == 9
+    # an invalid pair gives the same status on every rank
+    with pytest.raises(psa.PsaError) as ei:
+        ctx.score_range_allgather("A", 0, 1, None)
+    assert ei.value.status == 2
+
+
+def test_context_guards(psa):
+    """Seq1 and the table cannot be replaced under live batches; a context shut down before its
+    batches detaches them (C callers: the Python wrapper closes batches first by itself)."""
+    import ctypes as C
+    L = psa.lib()
+    h = C.c_void_p()
+    assert L.psa_init(0, C.byref(h)) == 0
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    assert L.psa_set_seq1(h, b"ABCDEFGHABCDEFGH", -1) == 0
+    assert L.psa_set_weights(h, w.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    arr = (C.c_char_p * 2)(b"ABCDEF", b"HGFEDCBA")
+    bh = C.c_void_p()
+    assert L.psa_batch_create(h, 2, arr, None, C.byref(bh)) == 0
+    assert L.psa_set_seq1(h, b"ABCD", -1) == 7  # PSA_ERR_STATE: a shorter Seq1 under a live batch
+    assert L.psa_set_weights(h, w.ctypes.data_as(C.POINTER(C.c_float))) == 7
+    assert L.psa_batch_run(bh, 0) == 0
+    out = (psa.Result * 2)()
+    assert L.psa_batch_results(bh, out) == 0 and out[0].n >= 1
+    assert L.psa_batch_enqueue(bh, 0) == 0  # a run nobody waits for
+    L.psa_shutdown(h)  # before the batch is destroyed
+    assert L.psa_batch_run(bh, 0) == 7 and L.psa_batch_results(bh, out) == 7 and L.psa_batch_wait(bh) == 7
+    L.psa_batch_destroy(bh)  # the only call still allowed on it
+    # with the batches gone both can be replaced
+    c = psa.Context(0)
+    c.set_seq1("ABCDEFGH")
+    c.set_weights(w)
+    b = c.batch(["ABCD"])
+    with pytest.raises(psa.PsaError):
+        c.set_seq1("ABCDEFGHIJ")
+    b.close()
+    c.set_seq1("ABCDEFGHIJ")
+    assert c.score_batch(["ABCDEFGHIJ"])[0].status == 0
+    c.close()
+
+
 def test_dropin_shim(psa, oracle, golden, capfd):
     """psa_calc_best_score has calc_best_score_CUDA's contract: returns and echoes the line."""
     case = [c for c in golden if c["name"] == "ref_s_input2.txt"][0]
@@ -369,6 +482,21 @@ def test_host_program_files(psa, golden, tmp_path):
         out2 = tmp_path / ("pyout_" + name)
         assert host.run(inp, str(out2), echo=False) == want
         assert open(out2).read().splitlines(keepends=True) == want
+    # one worker thread per GPU (as many as the box has, at most 2), Seq2 above 5000 characters: the
+    # kernels' large dynamic-LDS requests on every device a worker runs on
+    seq1, seq2s = synth_problem(55, 7000, [5200, 900, 6100, 300])
+    inp = tmp_path / "long_input.txt"
+    inp.write_text("2 1.5 1.1 1.3\n%s\n%d\n%s\n" % (seq1, len(seq2s), "\n".join(seq2s)))
+    out = tmp_path / "long_output.txt"
+    r = subprocess.run([exe, str(inp), str(out), "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    import oracle_py
+    table = oracle_py.comp_matrix(np.array([2, 1.5, 1.1, 1.3], dtype=np.float32))
+    want = []
+    for s2 in seq2s:
+        o = oracle_py.fast(seq1, s2, table)
+        want.append("mutant num: %d, MS(%d,%d), score: %1.2f, offset: %d\n" % (o.mutant_num, o.n, o.k, o.score, o.offset))
+    assert open(out).read().splitlines(keepends=True) == want
 
 
 def test_mpi_host_program(psa, golden, tmp_path):
@@ -387,6 +515,30 @@ def test_mpi_host_program(psa, golden, tmp_path):
         out = tmp_path / ("mpi_out_" + name)
         r = subprocess.run([mpiexec, "-np", str(ranks), exe, inp, str(out)], capture_output=True, text=True,
                            timeout=120, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr + r.stdout
+        want = _expected_lines(psa, case)
+        assert open(out).read().splitlines(keepends=True) == want
+        assert all(line in r.stdout for line in want)
+
+
+def test_mpi_host_program_long_pair(psa, golden, tmp_path):
+    """psa_mpi --long-pair: every Seq2 scored by all ranks together (offset shards, one MPI_Allgather
+    of one record per rank inside psa_score_range_allgather); the output is that of the normal mode."""
+    import os
+    import subprocess
+    from shutil import which
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "parallel-sequence-alignment_amd", "psa_mpi")
+    mpiexec = which("/opt/conda/bin/mpiexec") or which("mpiexec")
+    if mpiexec is None or not os.path.exists(exe):
+        pytest.skip("no MPI installation: psa_mpi is not built")
+    # (ref_s_input2: Seq1 = 46, Seq2 = 45 -> 4 offsets over 3 ranks; ref_p_input1: 5 and 3 offsets over 4 ranks)
+    for name, ranks in (("ref_input.txt", 2), ("ref_s_input3.txt", 3), ("ref_s_input2.txt", 3), ("ref_p_input1.txt", 4)):
+        case = [c for c in golden if c["name"] == name][0]
+        inp = os.path.join(root, "tests", "golden", "inputs", name)
+        out = tmp_path / ("mpi_lp_out_" + name)
+        r = subprocess.run([mpiexec, "-np", str(ranks), exe, "--long-pair", inp, str(out)], capture_output=True,
+                           text=True, timeout=120, cwd=str(tmp_path))
         assert r.returncode == 0, r.stderr + r.stdout
         want = _expected_lines(psa, case)
         assert open(out).read().splitlines(keepends=True) == want
@@ -416,11 +568,19 @@ def test_reference_host_program_bound_to_libpsa_hip(psa, golden, tmp_path):
         work = tmp_path / ("refhost_" + name)
         work.mkdir()
         shutil.copy(os.path.join(root, "tests", "golden", "inputs", name), work / "input.txt")
-        r = subprocess.run([mpiexec, "-np", "2", exe], capture_output=True, text=True, timeout=120, cwd=str(work))
+        env = dict(os.environ, PSA_DEBUG_SYNC="1")  # also makes the shim say which GPU each rank took
+        env.pop("PSA_DEVICE", None)
+        r = subprocess.run([mpiexec, "-np", "2", exe], capture_output=True, text=True, timeout=300, cwd=str(work), env=env)
         assert r.returncode == 0, r.stderr + r.stdout
         want = _expected_lines(psa, case)
         assert open(work / "output.txt").read().splitlines(keepends=True) == want
         assert all(line in r.stdout for line in want)  # the echo of P/cudaFunctions.cu:321
+        # one rank per GPU: each rank picks the GPU of its rank on the node (both GPU 0 on a one-GPU box)
+        import re
+        picks = re.findall(r"psa_calc_best_score: pid \d+ uses GPU (\d+) of (\d+)", r.stderr)
+        assert len(picks) == 2, r.stderr[-2000:]
+        ngpu = int(picks[0][1])
+        assert sorted(int(p[0]) for p in picks) == ([0, 1] if ngpu >= 2 else [0, 0])
 
 
 def test_config3_shape_small(psa, ctx, oracle):
@@ -546,6 +706,38 @@ def test_config3_batch_properties(psa, ctx, oracle):
     alone = ctx.score_batch([seq2s[sample[0]]])[0]
     assert alone.key() == res[sample[0]].key() and alone.enum_key() == res[sample[0]].enum_key()
     assert sum(r.candidates for r in res) == sum((10000 - L + 3) * (L * (L - 1) // 2) for L in lens)
+
+
+def test_config3_full_size(psa, oracle):
+    """BASELINE's batch at full size: 4096 Seq2 of 500..2000 characters against Seq1 = 10000 (3.0e13
+    candidates; dozens of slab passes, millions of chunks), in two orders; a seeded sample of 32
+    against the oracle; the split over 8 workers scored part by part gives the same records."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(3)
+    lens = [int(x) for x in rng.integers(500, 2001, size=4096)]
+    seq1, seq2s = synth_problem(3, 10000, lens)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    res = c.score_batch(seq2s)
+    assert all(r.status == 0 for r in res)
+    assert sum(r.candidates for r in res) == sum((10000 - L + 3) * (L * (L - 1) // 2) for L in lens)
+    sample = sorted(int(i) for i in rng.choice(len(seq2s), size=32, replace=False))
+    with ThreadPoolExecutor(max_workers=16) as ex:  # the oracle calls release the GIL
+        list(ex.map(lambda i: check_against_oracle(oracle, seq1, [seq2s[i]], table, [res[i]]), sample))
+    full = lambda r: r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) + (r.mutant_num, r.candidates)
+    perm = rng.permutation(len(seq2s))
+    res_p = c.score_batch([seq2s[i] for i in perm])
+    assert all(full(res_p[j]) == full(res[i]) for j, i in enumerate(perm))
+    del res_p
+    owner = psa.partition(lens, 10000, 8)
+    for part in (0, 7):  # two of the eight shares, each scored as its rank would score it
+        idx = [i for i in range(len(seq2s)) if owner[i] == part]
+        got = c.score_batch([seq2s[i] for i in idx])
+        assert all(full(g) == full(res[i]) for g, i in zip(got, idx))
+    c.close()
 
 
 def test_authors_recorded_output(psa):

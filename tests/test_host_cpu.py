@@ -63,10 +63,19 @@ def test_partition_balances_cost(psa):
     len2 = rng.integers(500, 2001, size=4096).astype(np.int32)
     L1 = 10000
     for parts in (1, 2, 4, 8):
-        owner = psa.partition(len2, L1, parts)
-        cost = (L1 - len2 + 3).astype(np.float64) * len2 * (len2 - 1) / 2
-        loads = np.array([cost[owner == p].sum() for p in range(parts)])
-        assert loads.min() > 0 and loads.max() / loads.mean() < 1.01
+        for stages in (0, psa.STAGE_RESOLVE):
+            owner = psa.partition(len2, L1, parts, stages)
+            cost = np.array([psa.cost_estimate(int(L), L1, stages) for L in len2])
+            loads = np.array([cost[owner == p].sum() for p in range(parts)])
+            assert loads.min() > 0 and loads.max() / loads.mean() <= 1.02
+    # the cost follows the candidate loop's measured efficiency, not the raw candidate count:
+    # candidates per predicted cycle rise with the Seq2 length (64 candidates per 4 cycles at the peak)
+    def eff(L2):
+        cand = (L1 - L2 + 3) * (L2 * (L2 - 1) // 2)
+        return cand / 64.0 * 4.0 / psa.cost_estimate(L2, L1, 0)
+    assert 0.62 < eff(512) < 0.72 and 0.80 < eff(2000) < 0.88 and eff(512) < eff(1000) < eff(2000) < eff(8000) < 1.0
+    assert psa.cost_estimate(1, L1, 0) == 0.0 and psa.cost_estimate(L1 + 3, L1, 0) == 0.0
+    assert psa.cost_estimate(700, L1, psa.STAGE_RESOLVE) == (L1 - 700 + 3) * 700.0
 
 
 def test_combine_results_tie_order(psa):
@@ -114,7 +123,7 @@ def test_mpi_host_split_dry_run(psa, np_ranks, tmp_path):
     got = [re.match(r"Seq2 #(\d+) \((\d+) characters\) -> rank (\d+)", l).groups() for l in lines[1:5]]
     lens = [138, 1202, 466, 377]
     assert [int(g[0]) for g in got] == [1, 2, 3, 4] and [int(g[1]) for g in got] == lens
-    owner = psa.partition(lens, 1489, np_ranks)
+    owner = psa.partition(lens, 1489, np_ranks, psa.STAGE_RESOLVE)
     assert [int(g[2]) for g in got] == list(owner)
     assert lines[5].startswith("Total Time: ")
     assert not (tmp_path / "unused.txt").exists()
