@@ -39,7 +39,8 @@ typedef enum psa_status {
   PSA_ERR_STATE = 7,      /* call out of order: Seq1 or the table not set, Seq1 or the table replaced while the
                              context has batches, a batch used after its context was shut down, wait without enqueue */
   PSA_ERR_NOMEM = 8,
-  PSA_ERR_COMM = 9        /* the caller's all-gather callback reported a failure */
+  PSA_ERR_COMM = 9,       /* the caller's all-gather callback reported a failure */
+  PSA_ERR_LIMIT = 10      /* beyond the fixed capacity of psa_score_range_noalloc */
 } psa_status;
 
 /* stages of one run; 0 means both */
@@ -163,6 +164,37 @@ int psa_score_range_allgather(psa_ctx *ctx, const char *seq2, int32_t len2, int 
  * in HBM. */
 int psa_batch_run_allgather(psa_batch *shard, int nranks, psa_allgather_fn allgather, void *comm,
                             uint32_t stages, psa_result *out);
+
+/* ---- one entry point that allocates nothing --------------------------------------------
+ * No counterpart in the reference (whose calc_best_score_CUDA allocates five device buffers per
+ * call and frees none, P/cudaFunctions.cu:273-288).  For callers that cannot allocate: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ *
+ * psa_score_range_noalloc is psa_score_range with the resolve stage (the reference's float32
+ * answer: n, k, offset, score bits, class counts), inputs and output already in device memory:
+ * d_seq1 and d_seq2 hold the characters 'A'..'Z' (no terminator needed), d_table the 26 x 26
+ * float table calc_best_score_CUDA receives, and the record is written to d_out (device memory,
+ * or pinned host memory the device can write).  The kernels are enqueued on `stream` (a
+ * hipStream_t; NULL = the default stream) of the current device and the call returns without
+ * waiting: the record is complete when the stream has run that far.  Every intermediate lives in
+ * one fixed array of PSA_NOALLOC_SCRATCH_BYTES (3.3 MiB) of device memory inside the library's
+ * code object, which every GPU the library is loaded on holds until the process ends.  The call
+ * makes no hipMalloc, hipFree or other allocating call.
+ * Limits: len1 <= PSA_NOALLOC_MAX_SEQ1 (else PSA_ERR_LIMIT), len2 <= PSA_MAX_SEQ2.  The
+ * enumeration fields of the record are cleared (enum_frac_bits = -1).  A character outside
+ * 'A'..'Z' is found on the device: the record then has status PSA_ERR_RESIDUE and nothing else.
+ * All calls on one GPU share that GPU's array: calls whose kernels could overlap (two streams,
+ * two threads) race; issue them on one stream or order them with events.
+ * psa_noalloc_init (optional; otherwise done by the first call on each device) looks up the
+ * array's address on the current device and sets the kernels' LDS limits there -- call it before
+ * a graph capture begins. */
+#define PSA_NOALLOC_MAX_SEQ1 262144
+#define PSA_NOALLOC_SCRATCH_BYTES 3430912
+int psa_noalloc_init(void);
+int psa_score_range_noalloc(const char *d_seq1, int64_t len1, const char *d_seq2, int32_t len2,
+                            const float *d_table, int64_t s_begin, int64_t s_end, void *stream,
+                            psa_result *d_out);
+const char *psa_noalloc_last_error_text(void);
 
 /* ---- the reference's host helpers ------------------------------------------------ */
 /* drop-in for  char* calc_best_score_CUDA(char*, char*, float*)  (P/myProto.h:20,

@@ -236,6 +236,7 @@ const char *psa_strerror(int status) {
     case PSA_ERR_STATE: return "call out of order (Seq1 or table not set, or replaced under live batches; batch without context; wait without enqueue)";
     case PSA_ERR_NOMEM: return "out of memory";
     case PSA_ERR_COMM: return "the caller's all-gather failed";
+    case PSA_ERR_LIMIT: return "beyond the fixed capacity of the entry point that allocates nothing";
     default: return "unknown status";
   }
 }
