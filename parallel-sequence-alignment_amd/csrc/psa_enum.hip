@@ -31,6 +31,8 @@
 // than the int32 pair, and float32 adds integers of at most 24 bits exactly, so the
 // default scale keeps f, g and f + g within 24 bits and the loop runs in float32; the
 // int32 form of the same kernels (30-bit values) is kept behind a switch.
+#include <stdlib.h>
+
 #include <hip/hip_ext.h>
 
 #include "psa_device.h"
@@ -367,6 +369,227 @@ __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int
   if (q < qb) wave_step16<R, R, F32>(ga, f, acc);
 }
 
+// ---- long phase on the matrix cores --------------------------------------------------
+// f[p] + g[q] for 32 q x 32 p is the product of a 32 x K and a K x 32 matrix whose entries are
+// pieces of the values and ones: sum_k A[q][k] B[k][p] with A = (1, 1, 1, g_hi, g_mid, g_lo),
+// B = (f_hi, f_mid, f_lo, 1, 1, 1).  f and g are integers of at most 25 significant bits held in
+// float32, so each splits exactly into three bfloat16 values (8 significant bits each): hi = the
+// value with its low 16 bits cleared, mid likewise of the remainder, lo the rest.  Every product
+// is exact, every partial sum of pieces is an integer no larger than the larger of |f|, |g| and
+// |f + g| <= 2^24, so the float32 accumulation inside v_mfma_f32_32x32x16_bf16 is exact in any
+// order and the tile holds the same 1024 integers the add instructions would give.  One such
+// instruction occupies the matrix core for 32 cycles and the vector issue port for 8; the 16
+// sums per lane then cost 8 v_max3_f32 (32 cycles), against 16 v_add_f32 + 8 v_max3_f32 for the
+// same 1024 candidates on the vector ALU alone (measured: 5.2 against 6.5 cycles per 128 candidates).
+//
+// Operand layout of v_mfma_f32_32x32x16_bf16 (lane l, r = l & 31, h = l >> 5): A[row r][k = 8h + j]
+// and B[k = 8h + j][col r] for element j = 0..7; result register v of lane l is row
+// (v & 3) + 8 (v >> 2) + 4h, column r.  Columns are positions p (a lane keeps the running maximum of
+// its own p over the rows, i.e. over q), rows are positions q.  The lower 32 lanes supply k = 0..7,
+// the upper 32 lanes k = 8..15: f's pieces sit in the lower lanes of B (against ones in A), g's
+// pieces in the upper lanes of A (against ones in B), so both halves of the operand registers
+// carry data and neither operand needs a lane of zeros:
+//   B: lower lanes (f_hi|f_mid), (f_lo|0), 0, 0      upper lanes (1|1), (1|1), 0, 0
+//   A: lower lanes (1|1), (1|1), 0, 0                upper lanes (g_hi|g_mid), (g_lo|0), 0, 0
+// A register that holds the packed pieces of 64 consecutive values (lane = position) turns into
+// the operand registers of its two blocks of 32 with one v_permlane32_swap_b32 against a register
+// of ones: the swap exchanges the upper half of one register with the lower half of the other.
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+constexpr int kOnesBf16 = 0x3f803f80;  // (1.0, 1.0) as two bfloat16
+
+// x = hi + mid + lo exactly; p0 = (hi | mid << 16), p1 = (lo | 0) as packed bfloat16
+__device__ __forceinline__ void split_bf16x3(int xbits, int &p0, int &p1) {
+  const float x = __int_as_float(xbits);
+  const int hi = xbits & (int)0xffff0000;
+  const float rem = x - __int_as_float(hi);
+  const int mid = __float_as_int(rem) & (int)0xffff0000;
+  const float lo = rem - __int_as_float(mid);
+  p0 = (int)__builtin_amdgcn_perm((unsigned)mid, (unsigned)hi, 0x07060302u);
+  p1 = (int)((unsigned)__float_as_int(lo) >> 16);
+}
+
+// B operands of the wave's 8 blocks of 32 positions p from its 4 registers of f (lane = position)
+__device__ __forceinline__ void mfma_build_b(const int (&f)[4], i32x4 (&B)[8]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int p0, p1;
+    split_bf16x3(f[r], p0, p1);
+    const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)kOnesBf16, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)p1, (unsigned)kOnesBf16, false, false);
+    B[2 * r] = i32x4{(int)s0[0], (int)s1[0], 0, 0};      // lower lanes: positions 64 r + 0..31
+    B[2 * r + 1] = i32x4{(int)s0[1], (int)s1[1], 0, 0};  // lower lanes: positions 64 r + 32..63
+  }
+}
+
+// one tile: 32 q (operand a) x 32 p (operand b) on top of c (zero, or the diagonal tile's mask);
+// running maxima of the lane's column
+__device__ __forceinline__ f32x16 mfma_sums(const i32x4 &a, const i32x4 &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_reduce(const f32x16 &d, float &m) {
+  // a tree over the 16 results, the running maximum joining last: 8 v_max3_f32
+  const float t0 = fmaxf(fmaxf(d[0], d[1]), d[2]);
+  const float t1 = fmaxf(fmaxf(d[3], d[4]), d[5]);
+  const float t2 = fmaxf(fmaxf(d[6], d[7]), d[8]);
+  const float t3 = fmaxf(fmaxf(d[9], d[10]), d[11]);
+  const float t4 = fmaxf(fmaxf(d[12], d[13]), d[14]);
+  const float u0 = fmaxf(fmaxf(t0, t1), t2);
+  const float u1 = fmaxf(fmaxf(t3, t4), d[15]);
+  m = fmaxf(fmaxf(m, u0), u1);
+}
+// N tiles that share the operand a (32 q) against blocks 0..N-1 of p, the last one on top of c_last:
+// the matrix core forms the sums of tile t + 1 while the vector ALU takes the maxima of tile t
+// (two result tiles in registers; the order is pinned, the compiler otherwise puts each tile's
+// maxima right behind its own matrix instruction and the wave idles through its latency).
+template <int N>
+__device__ __forceinline__ void mfma_tiles(const i32x4 &a, const i32x4 (&B)[8], const f32x16 &c_last, float (&m)[8]) {
+  const f32x16 z = {};
+  f32x16 d = mfma_sums(a, B[0], N == 1 ? c_last : z);
+#pragma unroll
+  for (int pb = 0; pb < N; ++pb) {
+    f32x16 dn = d;
+    if (pb + 1 < N) {
+      dn = mfma_sums(a, B[pb + 1], pb + 2 == N ? c_last : z);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_reduce(d, m[pb]);
+    __builtin_amdgcn_sched_barrier(0);
+    d = dn;
+  }
+}
+
+// A operands of the two blocks of 32 consecutive q whose g values the lanes hold (lane = position)
+__device__ __forceinline__ void mfma_build_a(int g, i32x4 &a0, i32x4 &a1) {
+  int p0, p1;
+  split_bf16x3(g, p0, p1);
+  const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)kOnesBf16, (unsigned)p0, false, false);
+  const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)kOnesBf16, (unsigned)p1, false, false);
+  a0 = i32x4{(int)s0[0], (int)s1[0], 0, 0};  // upper lanes: positions 0..31 of the 64
+  a1 = i32x4{(int)s0[1], (int)s1[1], 0, 0};  // upper lanes: positions 32..63
+}
+
+// The block of 32 q with index RB (0..7) inside the level's own 256 positions: every block of p
+// below it in full, and block RB itself along the diagonal, where only q > p exists: the mask
+// tile adds -2^30 to the other entries.
+template <int RB>
+__device__ __forceinline__ void mfma_own_block(const i32x4 &a, const i32x4 (&B)[8], const f32x16 &mask, float (&m)[8]) {
+  mfma_tiles<RB + 1>(a, B, mask, m);
+}
+
+// One unit with every candidate's sum formed on the matrix cores: sub-run j of chunk c at level w
+// (positions p in [256 w, 256 w + 256) as 8 blocks of 32; q from 256 w to the end of the row in
+// blocks of 32).  The row of an offset is read through per-lane loads of 64 consecutive values,
+// requested two steps ahead; f of an offset is the next offset's row minus that row's constant.
+__device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const WaveParams &P, int u, int lane) {
+  int w = 0;
+#pragma unroll
+  for (int i = 1; i < kEnumMaxLevels; ++i) w += (u >= P.level_base[i]) ? 1 : 0;
+  const int mu = u - P.level_base[w];
+  const int c = mu >> P.sub_log2, j = mu & ((1 << P.sub_log2) - 1);
+  const Chunk ch = load_chunk(P.chunks + c);
+  const SeqDesc d = load_desc(P.desc + ch.seq);
+  const int r0 = j * d.enum_ns;
+  if (r0 >= ch.ns) return;
+  const int r1 = min(r0 + d.enum_ns, ch.ns);
+  const int L2 = d.len2;
+  const int nruns = (L2 + 63) >> 6;
+  const int qend = 64 * nruns;   // row length
+  const int pc0 = 4 * w;         // first run of 64 positions p of this level
+  const int q00 = 64 * pc0;      // first position of the level
+  const int rowlen = qend + 64;  // a row of g and its run of padding
+  const int *__restrict__ G = fg + ((size_t)ch.fg_row + (size_t)r0 * (nruns + 1)) * 64;  // row of offset r0
+  const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, -1, 0x00020000);
+  // Register r of f holds run pc0 + r of p; past the last run it repeats that run (its maxima are dropped below).
+  int vb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vb[r] = 4 * (64 * min(pc0 + r, nruns - 1) + lane);
+  // mask of a diagonal tile: result register v of this lane is row (v & 3) + 8 (v >> 2) + 4 (lane >> 5), column lane & 31
+  f32x16 mask;
+#pragma unroll
+  for (int v = 0; v < 16; ++v)
+    mask[v] = ((v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)) > (lane & 31) ? 0.0f : __int_as_float(Cand<true>::lowest);
+  float m[8];
+#pragma unroll
+  for (int pb = 0; pb < 8; ++pb) m[pb] = __int_as_float(Cand<true>::lowest);
+  int soff = 0;  // byte offset of the current row
+  int fn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
+  int tn = G[rowlen + qend];  // the constant of the next row
+  for (int i = r0; i < r1; ++i) {
+    i32x4 B[8];
+    {
+      int f[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f[r] = Cand<true>::sub(fn[r], tn);
+      mfma_build_b(f, B);
+    }
+    const int grow = soff;  // this offset's row of g
+    soff += 4 * rowlen;
+    if (i + 1 < r1) {  // next offset's f values arrive while this one is scored
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
+      tn = G[2 * rowlen + qend];
+    }
+    G += rowlen;
+    int g0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), grow, 0);
+    int g1 = q00 + 64 < qend ? __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + 64 + lane), grow, 0) : 0;
+    int q = q00;
+    // the level's own 256 positions: blocks 0..7 of q against the blocks of p below and at them
+#define PSA_OWN_STEP(RB)                                                                            \
+    if (q < qend) {                                                                                   \
+      int g2 = 0;                                                                                     \
+      if (q + 128 < qend) g2 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q + 128 + lane), grow, 0); \
+      i32x4 a0, a1;                                                                                   \
+      mfma_build_a(g0, a0, a1);                                                                       \
+      mfma_own_block<RB>(a0, B, mask, m);                                                             \
+      if (q + 32 < L2) mfma_own_block<RB + 1>(a1, B, mask, m);                                        \
+      g0 = g1;                                                                                        \
+      g1 = g2;                                                                                        \
+      q += 64;                                                                                        \
+    }
+    PSA_OWN_STEP(0)
+    PSA_OWN_STEP(2)
+    PSA_OWN_STEP(4)
+    PSA_OWN_STEP(6)
+#undef PSA_OWN_STEP
+    // beyond them every (p, q) pair is a candidate
+    const f32x16 z = {};
+    for (; q < qend; q += 64) {
+      int g2 = 0;
+      if (q + 128 < qend) g2 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q + 128 + lane), grow, 0);
+      i32x4 a0, a1;
+      mfma_build_a(g0, a0, a1);
+      mfma_tiles<8>(a0, B, z, m);
+      if (q + 32 < L2) mfma_tiles<8>(a1, B, z, m);
+      g0 = g1;
+      g1 = g2;
+    }
+  }
+  // best fixed-point score of this unit and the smallest p attaining it; lanes l and l + 32 hold
+  // maxima of the same column over different rows and enter the reduction as they are
+  int bestv = INT_MIN;
+  uint32_t bestp = 0x7fffffffu;
+#pragma unroll
+  for (int pb = 0; pb < 8; ++pb) {
+    const int p = q00 + 32 * pb + (lane & 31);
+    const int a = (int)m[pb];
+    if (p <= L2 - 2 && a > bestv) {
+      bestv = a;
+      bestp = (uint32_t)p;
+    }
+  }
+  unsigned long long key = ((unsigned long long)((uint32_t)bestv ^ 0x80000000u) << 32) | (0xffffffffu - bestp);
+  key = wave_max_u64(key);
+  if (lane == 0) {
+    // a stale read can only be too small, which costs an atomic, never a result
+    if (key > P.chunk_best[c]) atomicMax(&P.chunk_best[c], key);  // lets the locate pass skip chunks
+    if (key > P.acc[ch.seq].enum_key) atomicMax(&P.acc[ch.seq].enum_key, key);
+  }
+}
+
 // The q run that coincides with a register's own p run: lane l holds p = q0 + l, so
 // q0 + i pairs only with lanes l < i.  Steps are taken two at a time: for even i the
 // lanes l < i take q0 + i and q0 + i + 1 in one max3; what that leaves out, lane i with
@@ -532,6 +755,15 @@ __global__ __launch_bounds__(512, 8) void psa_enum_wave(const int *__restrict__ 
   if (u < P.nunits) wave_unit<R, F32>(fg, P, u, lane);
 }
 
+// The same units with the long phase on the matrix cores (float32 arithmetic only).  The result
+// tiles and the operands of 8 blocks of positions take registers: 4 waves per SIMD instead of 8,
+// which this form does not need (its vector instructions are independent of the matrix core's).
+__global__ __launch_bounds__(512, 4) void psa_enum_wave_mfma(const int *__restrict__ fg, WaveParams P) {
+  const int lane = threadIdx.x & 63;
+  const int u = uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (u < P.nunits) wave_unit_mfma(fg, P, u, lane);
+}
+
 // waves per SIMD the locate kernel's register budget is sized for
 constexpr int enum_waves_per_simd(int nt, int r) { return nt * r > 4096 ? 4 : 8; }
 
@@ -647,7 +879,10 @@ hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int wa
   if (waves_per_group < 1 || waves_per_group > 8) return hipErrorInvalidValue;
   const dim3 grid((P.nunits + waves_per_group - 1) / waves_per_group), block(64 * waves_per_group);
   // the events ride on the kernel's own dispatch packet: no marker packets before or after it
-  if (f32)
+  static const bool use_mfma = !(getenv("PSA_ENUM_MFMA") && atoi(getenv("PSA_ENUM_MFMA")) == 0);  // tuning aid
+  if (f32 && use_mfma)
+    hipExtLaunchKernelGGL(psa_enum_wave_mfma, grid, block, lds_bytes, st, ev_start, ev_stop, 0, fg, P);
+  else if (f32)
     hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, true>), grid, block, lds_bytes, st,
                           ev_start, ev_stop, 0, fg, P);
   else
