@@ -53,6 +53,32 @@ WEIGHTS = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)  # the reference's inpu
 # clock 2400 MHz)
 PEAK_INT32_LANE_OPS = 256 * 4 * 32 * 2.4e9
 OPS_PER_CANDIDATE = 2  # one add (f[p] + g[q]) and one max per (offset, mutant) candidate
+# The candidate loop forms the sums of 32 x 32 candidates with one v_mfma_f32_32x32x16_bf16 and takes
+# their maxima with 8 v_max3_f32.  What bounds it is the SIMD's vector issue port: a v_max3_f32 takes
+# 4 cycles of it and the matrix instruction holds it for 8 of its 32 (MI355X_MICROARCH.md, cycle
+# constants: vector-instruction issue cost), so a tile cannot take less than 40 cycles of one SIMD;
+# measured with nothing else in the loop: 41.4 (tools/valu_bench10.hip, profiles/r02_valu_mfma_ceilings.txt).
+SIMDS = 256 * 4
+PEAK_CLOCK_HZ = 2.4e9
+ISSUE_CYCLES_PER_TILE = 40.0
+PEAK_CANDIDATES = SIMDS * PEAK_CLOCK_HZ * 1024.0 / ISSUE_CYCLES_PER_TILE  # 6.29e13 candidates/s
+
+
+def tiles_per_offset(L2):
+    """32 x 32 tiles the candidate loop works through for one offset of a Seq2 of L2 characters: per
+    level of 256 positions p the level's own 8 blocks of q meet 1, 2, .. 8 blocks of p (the last along
+    the diagonal), every later block of q all 8; rows are padded to 64 positions and a last block of
+    32 that holds no position is skipped."""
+    nruns = (L2 + 63) // 64
+    qend = 64 * nruns
+    tiles = 0
+    for q00 in range(0, qend, 256):
+        for q in range(q00, qend, 64):
+            rb = (q - q00) // 32
+            tiles += min(rb + 1, 8)
+            if q + 32 < L2:
+                tiles += min(rb + 2, 8)
+    return tiles
 
 
 def synth(seed, L1, L2s):
@@ -330,6 +356,17 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
         iso_enum_ms += em
         iso_gpu_ms += tm
     job.torch.cuda.synchronize()
+    # the clock the chip holds under this kernel: a few more steps with the candidate loop's stamped
+    # variant (its waves sum their shader cycles and 100 MHz ticks); no timing is taken from these
+    clock_mhz = 0.0
+    if stages & psa_amd.STAGE_ENUMERATE:
+        ctx.clock_probe(True)
+        t_probe = time.perf_counter()
+        while True:
+            batch.launch(stages)
+            if time.perf_counter() - t_probe > 0.05:
+                break
+        clock_mhz, _ = ctx.clock_probe(False)
 
     res = batch.results()
     bad_status = [r.status for r in res if r.status != 0]
@@ -399,7 +436,7 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
         "name": name, "scaling": scaling, "elapsed": elapsed, "steps": steps, "cand_total": cand_total,
         "cand_rank": cand_rank, "per_rank": per_rank, "answer": answer, "parity": parity, "complaints": complaints,
         "parity_checked": checked, "enum_ms": enum_ms, "gpu_ms": gpu_ms, "iso_enum_ms": iso_enum_ms,
-        "iso_gpu_ms": iso_gpu_ms, "n_iso": n_iso, "pipelined": pipelined, "stages": stages,
+        "iso_gpu_ms": iso_gpu_ms, "n_iso": n_iso, "pipelined": pipelined, "stages": stages, "clock_mhz": clock_mhz,
         "seq1": seq1, "seq2s": seq2s, "my_seq2": my_seq2, "res": res, "shard": shard,
     }
     return out
@@ -410,20 +447,19 @@ def roofline_block(cfg, w):
     steps, cand_rank = w["steps"], w["cand_rank"]
     # this rank's average candidate-loop kernel time per step, launches not sharing the GPU
     kern_s = (w["iso_enum_ms"] / w["n_iso"] if w["n_iso"] else w["enum_ms"] / steps) / 1e3
-    achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
     # slab rows the candidate loop reads: one 4-byte g per (offset, position); f of an offset is the
     # next offset's row (a chunk of 4 to 64 offsets stores one row more than it has offsets: not counted)
     if w["shard"] is None:
-        slab_bytes = sum(4.0 * len(s2) * (r.candidates / (len(s2) * (len(s2) - 1) // 2))
-                         for s2, r in zip(w["my_seq2"], w["res"]) if r.candidates > 0)
+        offsets = [r.candidates / (len(s2) * (len(s2) - 1) // 2) for s2, r in zip(w["my_seq2"], w["res"])]
     else:
-        slab_bytes = 4.0 * len(w["my_seq2"][0]) * (w["shard"][1] - w["shard"][0])
+        offsets = [float(w["shard"][1] - w["shard"][0])]
+    slab_bytes = sum(4.0 * len(s2) * n for s2, n in zip(w["my_seq2"], offsets))
     traffic, traffic_src = measured_traffic(cfg, slab_bytes)
     my_elapsed = w["per_rank"][0][0]
-    return {
-        "bound": "valu-32bit", "kernel": "psa_enum_wave",
-        "achieved": achieved / 1e12, "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s",
-        "frac": achieved / PEAK_INT32_LANE_OPS, "traffic": traffic,
+    lane_op_frac = cand_rank * OPS_PER_CANDIDATE / kern_s / PEAK_INT32_LANE_OPS
+    mfma = os.environ.get("PSA_ENUM_I32", "0") in ("", "0") and os.environ.get("PSA_ENUM_MFMA", "1") != "0"
+    common = {
+        "traffic": traffic,
         "traffic_unit": "bytes per launch from the committed rocprofv3 --pmc passes of this command (%s: FETCH_SIZE + "
                         "WRITE_SIZE, plus the half of the per-lane row reads that FETCH_SIZE does not count; "
                         "Infinity-Cache hits included); a constant read from that file, not measured by this run"
@@ -432,18 +468,51 @@ def roofline_block(cfg, w):
         # the same launch inside the timed region, where it shares the GPU with the launch
         # of the step before or after it (null when steps are awaited one by one: no sharing)
         "kernel_ms_pipelined": w["enum_ms"] / steps if w["pipelined"] else None,
-        # the same fraction with the whole step in the denominator (pre-pass, locate,
-        # records and every gap included)
-        "step_frac": cand_rank * OPS_PER_CANDIDATE * steps / my_elapsed / PEAK_INT32_LANE_OPS,
         "hbm_bytes_algorithmic": slab_bytes,
         "hbm_frac": slab_bytes / kern_s / 8.0e12,
-        "note": "2 lane-ops (add + max) per candidate x candidates per step / HIP-event time of the "
-                "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on "
-                "their stream, measured on steps launched one at a time after the timed region "
-                "(inside it two launches share the GPU: kernel_ms_pipelined); the kernel reads 4 bytes "
-                "of slab per (offset, position) against L2/2 candidates each (hbm_frac of the 8 TB/s "
-                "peak), so 32-bit VALU issue bounds it, not HBM or MFMA",
+        # the fraction this line carried before the sums moved to the matrix cores: 2 lane-ops (add +
+        # max) per candidate against 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz; above 1 now, because
+        # the adds no longer run on the vector ALU
+        "lane_op_frac": lane_op_frac,
     }
+    if not mfma:
+        achieved = cand_rank * OPS_PER_CANDIDATE / kern_s
+        return dict(common, **{
+            "bound": "valu-32bit", "kernel": "psa_enum_wave", "achieved": achieved / 1e12,
+            "peak": PEAK_INT32_LANE_OPS / 1e12, "unit": "Tlane-op/s", "frac": lane_op_frac,
+            "step_frac": cand_rank * OPS_PER_CANDIDATE * steps / my_elapsed / PEAK_INT32_LANE_OPS,
+            "note": "vector-ALU form of the candidate loop (PSA_ENUM_MFMA=0 or int32 arithmetic): 2 lane-ops (add + "
+                    "max) per candidate against the 32-bit VALU peak"})
+    tiles = sum(tiles_per_offset(len(s2)) * n for s2, n in zip(w["my_seq2"], offsets))
+    achieved = cand_rank / kern_s
+    clk = w["clock_mhz"] * 1e6
+    cyc_per_tile = kern_s * clk * SIMDS / tiles if clk > 0 else None
+    return dict(common, **{
+        "bound": "valu-issue", "kernel": "psa_enum_wave_mfma",
+        "achieved": achieved / 1e12, "peak": PEAK_CANDIDATES / 1e12, "unit": "Tcandidates/s",
+        "frac": achieved / PEAK_CANDIDATES,
+        # the same with the whole step in the denominator (pre-pass, locate, records and every gap included)
+        "step_frac": cand_rank * steps / my_elapsed / PEAK_CANDIDATES,
+        # clock the chip held under this kernel (its waves' shader cycles / 100 MHz ticks, measured by this run)
+        "clock_mhz_measured": w["clock_mhz"],
+        "tiles_per_launch": tiles,
+        "candidates_per_tile": cand_rank / tiles,
+        "issue_ceiling_cycles_per_tile": ISSUE_CYCLES_PER_TILE,
+        "cycles_per_tile_measured": cyc_per_tile,
+        # how close the kernel's tiles come to the issue ceiling, at the clock it really ran at: <= 1 by construction
+        "issue_frac_at_measured_clock": ISSUE_CYCLES_PER_TILE / cyc_per_tile if cyc_per_tile else None,
+        "frac_at_measured_clock": achieved / (PEAK_CANDIDATES * clk / PEAK_CLOCK_HZ) if clk > 0 else None,
+        "matrix_core_busy_frac": tiles * 32.0 / (kern_s * clk * SIMDS) if clk > 0 else None,
+        "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz x 1024 candidates per 40 cycles of vector issue (one "
+                "v_mfma_f32_32x32x16_bf16 holding the port for 8 cycles + 8 v_max3_f32 at 4: the kernel's own "
+                "instruction mix, nothing else); achieved = candidates per launch / HIP-event time of the "
+                "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on their stream, "
+                "measured on steps launched one at a time after the timed region (inside it two launches share "
+                "the GPU: kernel_ms_pipelined).  frac counts candidates, so tiles along the diagonal (half "
+                "empty) and row padding weigh against it; issue_frac_at_measured_clock counts tiles at the "
+                "measured clock.  The kernel reads 4 bytes of slab per (offset, position) against L2/2 "
+                "candidates each (hbm_frac of the 8 TB/s peak): vector issue bounds it, not HBM, and the "
+                "matrix cores are busy matrix_core_busy_frac of the time"})
 
 
 def host_inclusive(ctx, seq1, seq2s, calls=20):

@@ -103,6 +103,14 @@ int psa_set_weights(psa_ctx *ctx, const float weights[4]);
 /* any 26x26 float table, the argument calc_best_score_CUDA receives (P/myProto.h:20) */
 int psa_set_table(psa_ctx *ctx, const float table[PSA_TABLE_SIZE]);
 
+/* Measurement aid, no counterpart in the reference.  While enabled, the candidate loops of the
+ * context's runs are launched in a variant whose waves add the shader cycles and the 100 MHz ticks
+ * they lived to two counters; the call waits for the GPU, returns the clock the chip held over the
+ * runs since the last call (cycles / ticks x 100 MHz; 0 if no such run) and the mean wave cycles
+ * per unit of work, clears the counters and sets the mode for the runs that follow.  Float32
+ * matrix-core candidate loop only (the default); timings taken with the probe on are not quoted. */
+int psa_clock_probe(psa_ctx *ctx, int enable, double *clock_mhz, double *wave_cycles_per_unit);
+
 /* ---- batches of Seq2 ------------------------------------------------------------
  * Replaces the per-Seq2 loop around calc_best_score_CUDA (P/main.c:79-84, :128-135).
  * len2 may be NULL (then every seq2[i] is NUL-terminated). */
@@ -217,10 +225,11 @@ int64_t psa_mutant_number(int n, int k, int len2);
 char *psa_format_result(const psa_result *r);
 /* work split replacing calcPortion (P/cFunctions.c:49-52): assigns each Seq2 to one of nparts
  * workers (owner[i] in [0, nparts)), largest first onto the least loaded, balancing the predicted
- * GPU time of the stages that will run (0 = both): with the enumeration stage a model of the
- * candidate loop, whose candidates per cycle rise with the Seq2 length (0.67 of the peak rate at
- * 512 characters, 0.84 at 2000), not the raw candidate count; with the resolve stage alone
- * offsets x length.  psa_partition is psa_partition_stages with stages = 0. */
+ * GPU time of the stages that will run (0 = both): with the enumeration stage the number of
+ * 32 x 32 tiles the candidate loop works through, which per candidate falls with the Seq2 length
+ * (diagonal tiles, padding and per-offset set-up weigh more on a short Seq2), not the raw
+ * candidate count; with the resolve stage alone offsets x length.  psa_partition is
+ * psa_partition_stages with stages = 0. */
 int psa_partition(int n, const int32_t *len2, int64_t len1, int nparts, int32_t *owner);
 int psa_partition_stages(int n, const int32_t *len2, int64_t len1, int nparts, uint32_t stages, int32_t *owner);
 /* the cost that split balances, for one Seq2 (cycles of one SIMD; 0 for an invalid length) */

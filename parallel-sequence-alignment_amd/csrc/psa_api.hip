@@ -90,6 +90,8 @@ struct psa_ctx {
   float *d_table_t = nullptr;          // [27][32] floats, [seq2 code][seq1 code]
   unsigned char *d_class_t = nullptr;  // [27][32] class digits
   std::vector<Bundle *> spare;         // bundles of destroyed batches
+  unsigned long long *d_probe = nullptr;  // clock probe of the candidate loop: cycles, 100 MHz ticks, units
+  bool probe_on = false;
   // Batches created on this context and not yet destroyed.  A batch keeps values derived from
   // Seq1 and the table (offset ranges, forward blocks, the fixed-point scale), so neither may be
   // replaced while one exists; psa_shutdown detaches the ones a caller left behind.
@@ -139,6 +141,7 @@ struct psa_batch {
   // and the records of the run before are still reading theirs.
   int acc_par = 0;
   bool cap_loops = true;  // the candidate loops leave room on every CU for the short kernels (small batches)
+  bool mfma_loop = true;  // the candidate loop runs on the matrix cores (float32 arithmetic, the default)
   hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset: end of that run's record kernel
   bool tail_recorded[2] = {false, false};
   int tail_stream[2] = {0, 0};                 // the candidate-loop stream that event is on
@@ -206,6 +209,8 @@ int psa_init(int device, psa_ctx **out) {
   for (hipEvent_t &e : c->ev_prep) PSA_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP_C(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP_C(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
+  PSA_HIP_C(hipMalloc((void **)&c->d_probe, 3 * sizeof(unsigned long long)));
+  PSA_HIP_C(hipMemset(c->d_probe, 0, 3 * sizeof(unsigned long long)));
   std::vector<unsigned char> cls(psa::kDevTable, 3);
   for (int b = 0; b < 26; ++b)
     for (int a = 0; a < 26; ++a) cls[b * psa::kRowStride + a] = (unsigned char)psa::residue_class_code(a, b);
@@ -233,6 +238,7 @@ void psa_shutdown(psa_ctx *c) {
   if (c->d_seq1) (void)hipFree(c->d_seq1);
   if (c->d_table_t) (void)hipFree(c->d_table_t);
   if (c->d_class_t) (void)hipFree(c->d_class_t);
+  if (c->d_probe) (void)hipFree(c->d_probe);
   for (hipStream_t st : c->st_enum)
     if (st) (void)hipStreamDestroy(st);
   if (c->st_res) (void)hipStreamDestroy(c->st_res);
@@ -287,6 +293,19 @@ int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
   PSA_HIP(hipDeviceSynchronize());  // runs enqueued and not yet waited for still read the old table
   PSA_HIP(hipMemcpy(c->d_table_t, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
   c->have_table = true;
+  return PSA_OK;
+}
+
+int psa_clock_probe(psa_ctx *c, int enable, double *clock_mhz, double *wave_cycles_per_unit) {
+  if (!c) return PSA_ERR_ARG;
+  PSA_HIP(hipSetDevice(c->device));
+  PSA_HIP(hipDeviceSynchronize());
+  unsigned long long v[3] = {0, 0, 0};
+  PSA_HIP(hipMemcpy(v, c->d_probe, sizeof v, hipMemcpyDeviceToHost));
+  PSA_HIP(hipMemset(c->d_probe, 0, sizeof v));
+  if (clock_mhz) *clock_mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
+  if (wave_cycles_per_unit) *wave_cycles_per_unit = v[2] ? (double)v[0] / (double)v[2] : 0.0;
+  c->probe_on = enable != 0;
   return PSA_OK;
 }
 
@@ -417,10 +436,15 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   }
   // enough units to keep every wave slot busy many times over, each unit long enough
   // (about 30 us: 72000 cycles at ~333 cycles per 64 x 64 candidates) to hide its start-up;
-  // a batch too small for that still gets about two rounds of units over the wave slots (for
-  // Seq1 = 3000, 4 x Seq2 = 2000: two offsets per unit, 5 % faster than one or four)
-  const int64_t slots = (int64_t)c->num_cus * 32;
-  const int64_t ns_cap = std::max<int64_t>({1, row_units / (16 * slots), std::min<int64_t>(2, (row_units + slots) / (2 * slots))});
+  // a batch too small for that still gets two to three rounds of units over the wave slots (for
+  // Seq1 = 3000, 4 x Seq2 = 2000: three offsets per unit; two or four are 4 to 7 % slower).
+  // The matrix-core candidate loop runs 4 waves per SIMD, the vector-ALU one 8.
+  const bool mfma_loop = c->enum_f32 && !(std::getenv("PSA_ENUM_MFMA") && std::atoi(std::getenv("PSA_ENUM_MFMA")) == 0);
+  b->mfma_loop = mfma_loop;
+  const int64_t slots = (int64_t)c->num_cus * (mfma_loop ? 16 : 32);
+  const int64_t ns_small = mfma_loop ? std::min<int64_t>(4, (2 * row_units) / (5 * slots))
+                                     : std::min<int64_t>(2, (row_units + slots) / (2 * slots));
+  const int64_t ns_cap = std::max<int64_t>({1, row_units / (16 * slots), ns_small});
   // A batch with many rounds of units per wave slot lets its candidate loops take every wave
   // slot (8 waves per SIMD: 7 to 10 % faster than 6); the short kernels of the other streams then
   // move in as workgroups retire, which delays them by a few unit times -- nothing against such
@@ -429,7 +453,10 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   int min_ns = psa::kEnumMaxNs;
   for (int i : order) {
     psa::SeqDesc &d = b->desc[(size_t)i];
-    const int64_t unit_cycles = (int64_t)std::max(1, runs_of(d.len2) - RW) * RW * 333;
+    // cycles of the longest level of one offset: 64 x 64 blocks at ~333 cycles on the vector ALU,
+    // or 32 x 32 tiles at ~46 on the matrix cores (8 per block of 32 q beyond the level's own 256, 36 inside)
+    const int64_t unit_cycles = mfma_loop ? ((int64_t)std::max(0, 2 * runs_of(d.len2) - 8) * 8 + 36) * 46
+                                          : (int64_t)std::max(1, runs_of(d.len2) - RW) * RW * 333;
     int64_t ns = std::min<int64_t>(std::max<int64_t>(1, (72000 + unit_cycles / 2) / unit_cycles), ns_cap);
     if (const char *e = std::getenv("PSA_ENUM_NS")) ns = std::atoi(e);  // tuning aid
     d.enum_ns = (int32_t)std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
@@ -750,14 +777,18 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       W.chunk_best = chunk_best + sp.c0;
       W.desc = b->d_desc;
       W.acc = eacc;
+      W.clock_probe = c->probe_on ? c->d_probe : nullptr;
       // 41 KB of LDS per workgroup (untouched) keep the candidate loops, two of which may be in
       // flight, to three workgroups of 8 waves per CU between them: the short kernels of the
       // other streams always find wave slots, registers and LDS
-      int lds = b->cap_loops ? 41 * 1024 : 0;
+      const bool mfma_loop = b->mfma_loop;
+      int lds = b->cap_loops && !mfma_loop ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
       // capped launches keep workgroups of 8 waves (the cap counts workgroups); the others use
       // workgroups of one wave, which take a wave slot as soon as one is free
-      int wpg = b->cap_loops ? 8 : 1;
+      // (the matrix-core loop is capped by its registers at 4 waves per SIMD; small batches run it in
+      // workgroups of 4 waves: 0.180 against 0.190 ms per step of 4 x Seq2 = 2000 with 8-wave workgroups)
+      int wpg = b->cap_loops ? (mfma_loop ? 4 : 8) : 1;
       if (const char *e = std::getenv("PSA_ENUM_WPG")) wpg = std::max(1, std::min(8, std::atoi(e)));  // tuning aid
       PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;

@@ -482,7 +482,15 @@ __device__ __forceinline__ void mfma_own_block(const i32x4 &a, const i32x4 (&B)[
 // (positions p in [256 w, 256 w + 256) as 8 blocks of 32; q from 256 w to the end of the row in
 // blocks of 32).  The row of an offset is read through per-lane loads of 64 consecutive values,
 // requested two steps ahead; f of an offset is the next offset's row minus that row's constant.
+template <bool STAMP>
 __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const WaveParams &P, int u, int lane) {
+  // diagnostic build only: shader cycles and 100 MHz ticks this unit took, summed over all units,
+  // give the clock the chip held while the kernel ran
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if constexpr (STAMP) {
+    stamp_c = __builtin_amdgcn_s_memtime();
+    stamp_r = __builtin_amdgcn_s_memrealtime();
+  }
   int w = 0;
 #pragma unroll
   for (int i = 1; i < kEnumMaxLevels; ++i) w += (u >= P.level_base[i]) ? 1 : 0;
@@ -518,6 +526,9 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
 #pragma unroll
   for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
   int tn = G[rowlen + qend];  // the constant of the next row
+  // the first two steps of an offset's row of g are requested while the offset before is scored
+  int gfirst0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), soff, 0);
+  int gfirst1 = q00 + 64 < qend ? __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + 64 + lane), soff, 0) : 0;
   for (int i = r0; i < r1; ++i) {
     i32x4 B[8];
     {
@@ -534,8 +545,11 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
       tn = G[2 * rowlen + qend];
     }
     G += rowlen;
-    int g0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), grow, 0);
-    int g1 = q00 + 64 < qend ? __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + 64 + lane), grow, 0) : 0;
+    int g0 = gfirst0, g1 = gfirst1;
+    if (i + 1 < r1) {
+      gfirst0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), soff, 0);
+      if (q00 + 64 < qend) gfirst1 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + 64 + lane), soff, 0);
+    }
     int q = q00;
     // the level's own 256 positions: blocks 0..7 of q against the blocks of p below and at them
 #define PSA_OWN_STEP(RB)                                                                            \
@@ -587,6 +601,15 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     // a stale read can only be too small, which costs an atomic, never a result
     if (key > P.chunk_best[c]) atomicMax(&P.chunk_best[c], key);  // lets the locate pass skip chunks
     if (key > P.acc[ch.seq].enum_key) atomicMax(&P.acc[ch.seq].enum_key, key);
+  }
+  if constexpr (STAMP) {
+    stamp_c = __builtin_amdgcn_s_memtime() - stamp_c;
+    stamp_r = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    if (lane == 0) {
+      atomicAdd(&P.clock_probe[0], stamp_c);
+      atomicAdd(&P.clock_probe[1], stamp_r);
+      atomicAdd(&P.clock_probe[2], 1ull);
+    }
   }
 }
 
@@ -758,10 +781,11 @@ __global__ __launch_bounds__(512, 8) void psa_enum_wave(const int *__restrict__ 
 // The same units with the long phase on the matrix cores (float32 arithmetic only).  The result
 // tiles and the operands of 8 blocks of positions take registers: 4 waves per SIMD instead of 8,
 // which this form does not need (its vector instructions are independent of the matrix core's).
+template <bool STAMP>
 __global__ __launch_bounds__(512, 4) void psa_enum_wave_mfma(const int *__restrict__ fg, WaveParams P) {
   const int lane = threadIdx.x & 63;
   const int u = uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-  if (u < P.nunits) wave_unit_mfma(fg, P, u, lane);
+  if (u < P.nunits) wave_unit_mfma<STAMP>(fg, P, u, lane);
 }
 
 // waves per SIMD the locate kernel's register budget is sized for
@@ -880,8 +904,10 @@ hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int wa
   const dim3 grid((P.nunits + waves_per_group - 1) / waves_per_group), block(64 * waves_per_group);
   // the events ride on the kernel's own dispatch packet: no marker packets before or after it
   static const bool use_mfma = !(getenv("PSA_ENUM_MFMA") && atoi(getenv("PSA_ENUM_MFMA")) == 0);  // tuning aid
-  if (f32 && use_mfma)
-    hipExtLaunchKernelGGL(psa_enum_wave_mfma, grid, block, lds_bytes, st, ev_start, ev_stop, 0, fg, P);
+  if (f32 && use_mfma && P.clock_probe)
+    hipExtLaunchKernelGGL(psa_enum_wave_mfma<true>, grid, block, lds_bytes, st, ev_start, ev_stop, 0, fg, P);
+  else if (f32 && use_mfma)
+    hipExtLaunchKernelGGL(psa_enum_wave_mfma<false>, grid, block, lds_bytes, st, ev_start, ev_stop, 0, fg, P);
   else if (f32)
     hipExtLaunchKernelGGL((psa_enum_wave<kEnumWaveRuns, true>), grid, block, lds_bytes, st,
                           ev_start, ev_stop, 0, fg, P);

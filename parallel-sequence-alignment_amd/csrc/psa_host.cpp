@@ -133,29 +133,30 @@ int64_t mutant_of_nk(int n, int k, int len2) { return row_start(n, len2) + (k - 
 
 // Predicted cost of one Seq2, in cycles of one SIMD.
 //
-// Enumeration stage: the candidate loop scores 64 candidates (one q against one register of 64
-// positions p) in 4 cycles at the peak issue rate; measured on MI355X it needs about 4.3 in the
-// long phase (vector operands), 4.6 for the full blocks inside a level's own 256 positions (scalar
-// operands), 6 along the diagonal (half of those candidates do not exist), and about 580 cycles
-// per (offset, level) for the scalar and per-lane loads and their waits.  Candidates per cycle
-// therefore fall with the Seq2 length: 0.67 of the peak at 512 characters, 0.84 at 2000, 0.95 at
-// 8000 -- a split by raw candidate counts gives the rank with the short Seq2 more time than work.
+// Enumeration stage: the candidate loop works in tiles of 32 q x 32 p (one matrix instruction
+// and 8 v_max3_f32: 40 cycles of vector issue, about 45 measured with operand building, loads and
+// hazard padding).  Per offset and level (256 positions p) it walks the row of g from the level's
+// first position to the row's end: the level's own 8 blocks of q meet 1, 2, ... 8 blocks of p
+// (the last of each along the diagonal, where half of the tile is not a candidate), every later
+// block of q meets all 8; a row is padded to a multiple of 64 positions, of which the last 32 are
+// skipped when they hold no position of Seq2.  About 300 cycles per (offset, level) go into the
+// operands of p and the first loads.  Tiles per candidate therefore fall with the Seq2 length --
+// a split by raw candidate counts gives the rank with the short Seq2 more time than work.
 // Resolve stage alone: one dependent float32 chain step per (offset, position).
 double cost_estimate(int64_t len2, int64_t len1, uint32_t stages) {
   const int64_t S = len1 - len2 + 3;
   if (S <= 0 || len2 < 2) return 0.0;
   if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   if (!(stages & PSA_STAGE_ENUMERATE)) return double(S) * double(len2);
-  const int64_t nruns = (len2 + 63) / 64, qlast = (len2 + 15) & ~int64_t(15);
-  double cyc = 0.0;
-  for (int64_t pc0 = 0; pc0 < nruns; pc0 += 4) {
-    const int64_t long_q = std::max<int64_t>(0, qlast - 64 * (pc0 + 4));
-    const int64_t present = std::min<int64_t>(4, nruns - pc0);
-    cyc += 4.3 * 4.0 * double(long_q);                                                  // long phase, 4 registers
-    cyc += 4.6 * 64.0 * double(present * (present - 1) / 2) + 6.0 * 64.0 * double(present);  // own block
-    cyc += 580.0 * double(present) / 4.0;
-  }
-  return double(S) * cyc;
+  const int64_t nruns = (len2 + 63) / 64, qend = 64 * nruns;
+  int64_t tiles = 0, levels = 0;
+  for (int64_t q00 = 0; q00 < qend; q00 += 256, ++levels)
+    for (int64_t q = q00; q < qend; q += 64) {
+      const int64_t rb = (q - q00) / 32;  // index of the first of the two blocks of q inside the level
+      tiles += std::min<int64_t>(rb + 1, 8);
+      if (q + 32 < len2) tiles += std::min<int64_t>(rb + 2, 8);
+    }
+  return double(S) * (45.0 * double(tiles) + 300.0 * double(levels));
 }
 
 // Longest-processing-time assignment on the predicted cost of each Seq2.

@@ -80,6 +80,7 @@ def lib():
     L.psa_set_seq1.argtypes = [vp, C.c_char_p, C.c_int64]
     L.psa_set_weights.argtypes = [vp, f32p]
     L.psa_set_table.argtypes = [vp, f32p]
+    L.psa_clock_probe.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.psa_batch_create.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.POINTER(vp)]
     L.psa_batch_create_range.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(vp)]
     L.psa_batch_run.argtypes = [vp, C.c_uint32]
@@ -285,6 +286,13 @@ class Context:
         t = np.ascontiguousarray(table, dtype=np.float32)
         assert t.size == PSA_TABLE_SIZE
         _check(lib().psa_set_table(self._h, t.ctypes.data_as(C.POINTER(C.c_float))), "psa_set_table")
+
+    def clock_probe(self, enable):
+        """Reads (clock MHz, wave cycles per unit) of the candidate loops run since the last call with
+        the probe on, clears the counters, and switches the probe on or off for the runs that follow."""
+        mhz, cyc = C.c_double(), C.c_double()
+        _check(lib().psa_clock_probe(self._h, 1 if enable else 0, C.byref(mhz), C.byref(cyc)), "psa_clock_probe")
+        return mhz.value, cyc.value
 
     def batch(self, seq2s):
         return Batch(self, seq2s)

@@ -68,12 +68,12 @@ def test_partition_balances_cost(psa):
             cost = np.array([psa.cost_estimate(int(L), L1, stages) for L in len2])
             loads = np.array([cost[owner == p].sum() for p in range(parts)])
             assert loads.min() > 0 and loads.max() / loads.mean() <= 1.02
-    # the cost follows the candidate loop's measured efficiency, not the raw candidate count:
-    # candidates per predicted cycle rise with the Seq2 length (64 candidates per 4 cycles at the peak)
+    # the cost follows the candidate loop's tile count, not the raw candidate count: candidates per
+    # predicted cycle rise with the Seq2 length (1024 candidates per 40 cycles at the issue ceiling)
     def eff(L2):
         cand = (L1 - L2 + 3) * (L2 * (L2 - 1) // 2)
-        return cand / 64.0 * 4.0 / psa.cost_estimate(L2, L1, 0)
-    assert 0.62 < eff(512) < 0.72 and 0.80 < eff(2000) < 0.88 and eff(512) < eff(1000) < eff(2000) < eff(8000) < 1.0
+        return cand / 1024.0 * 40.0 / psa.cost_estimate(L2, L1, 0)
+    assert 0.70 < eff(512) < 0.80 and 0.82 < eff(2000) < 0.89 and eff(512) < eff(1000) < eff(2000) < eff(8000) < 0.89
     assert psa.cost_estimate(1, L1, 0) == 0.0 and psa.cost_estimate(L1 + 3, L1, 0) == 0.0
     assert psa.cost_estimate(700, L1, psa.STAGE_RESOLVE) == (L1 - 700 + 3) * 700.0
 
