@@ -102,10 +102,10 @@ def synth(seed, L1, L2s):
     return seq1, out
 
 
-def c3_list(nseq2):
+def c3_list(nseq2, lo=500, hi=2000):
     """The one seeded list of the c3 workload (the same on every rank)."""
     rng = np.random.default_rng(3)
-    lens = [int(x) for x in rng.integers(500, 2001, size=nseq2)]
+    lens = [int(x) for x in rng.integers(lo, hi + 1, size=nseq2)]
     return synth(3, 10000, lens)
 
 
@@ -281,14 +281,15 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
     elif cfg == "c3":
         # rank 0 makes the list and hands it out, as the reference's rank 0 reads input.txt and sends
         # the sequences (P/main.c:43-76); every rank then computes the same split
-        payload = [c3_list(nseq2) if rank == 0 else None]
+        payload = [c3_list(nseq2, args.len_lo, args.len_hi) if rank == 0 else None]
         if job.dist is not None:
             job.dist.broadcast_object_list(payload, src=0)
         seq1, seq2s = payload[0]
         owner = psa_amd.partition([len(s) for s in seq2s], len(seq1), world, stages)
         mine = [i for i in range(len(seq2s)) if owner[i] == rank]
         my_seq2 = [seq2s[i] for i in mine]
-        name = "C3: Seq1=10000, one list of %d Seq2 in [500,2000] split over %d GPU(s) by psa_partition" % (nseq2, world)
+        name = "C3: Seq1=10000, one list of %d Seq2 in [%d,%d] split over %d GPU(s) by psa_partition" % (
+            nseq2, args.len_lo, args.len_hi, world)
         scaling = "strong"
     elif cfg == "c4":
         seq1, seq2s = synth(4, 200000, [8000])
@@ -569,6 +570,8 @@ def main():
                          "measures the ramp: 0.27 instead of 0.22 ms per C2 step)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4"])
     ap.add_argument("--nseq2", type=int, default=4096, help="length of the Seq2 list of --config c3 (whole job)")
+    ap.add_argument("--len-lo", type=int, default=500, help="shortest Seq2 of --config c3 (BASELINE: 500)")
+    ap.add_argument("--len-hi", type=int, default=2000, help="longest Seq2 of --config c3 (BASELINE: 2000)")
     ap.add_argument("--stages", default="both", choices=["both", "enumerate", "resolve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale", action="store_true", help="skip the scale block (c3 and c4) of the default run")

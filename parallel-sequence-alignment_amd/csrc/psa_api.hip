@@ -42,7 +42,7 @@ struct Bundle {
   unsigned char *pin_dev = nullptr;  // the device's address of pin
   size_t pin_cap = 0;
   hipEvent_t ev[8] = {};
-  std::vector<hipEvent_t> pass_ev;  // 4 per slab pass
+  std::vector<hipEvent_t> pass_ev;  // 2 per slab pass and slab
 };
 
 void bundle_free(Bundle *u) {
@@ -57,6 +57,7 @@ void bundle_free(Bundle *u) {
 }
 
 constexpr size_t kMaxCachedBundles = 4;
+constexpr int kMaxSlabs = 3;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -76,12 +77,17 @@ struct psa_ctx {
   // the chip issues float add + max3 faster than the integer pair) or int32 with 30-bit values
   // (PSA_ENUM_I32=1, 6 more fractional bits in the fixed-point table).
   bool enum_f32 = true;
-  int *d_slab[2] = {nullptr, nullptr};
+  // Slabs of g rows.  Three: with two, the candidate loops of consecutive passes start as soon as
+  // their pre-passes are done, share the GPU, end together, and both slabs wait for their
+  // pre-passes while nothing else can run (a tenth of the time on many-pass batches); the third
+  // slab is filled while a pair of loops runs, so a loop is always ready when one ends.
+  int nslabs = kMaxSlabs;
+  int *d_slab[kMaxSlabs] = {};
   size_t slab_units = 0;  // capacity of each slab in runs of 64 int32
   int slab_count = 0;
-  hipEvent_t ev_prep[2] = {nullptr, nullptr};
-  hipEvent_t slab_reader[2] = {nullptr, nullptr};  // end of the last candidate loop that read slab i (a batch's event)
-  psa_batch *slab_reader_batch[2] = {nullptr, nullptr};
+  hipEvent_t ev_prep[kMaxSlabs] = {};
+  hipEvent_t slab_reader[kMaxSlabs] = {};  // end of the last candidate loop that read slab i (a batch's event)
+  psa_batch *slab_reader_batch[kMaxSlabs] = {};
   int slab_flip = 0;
   unsigned char *d_seq1 = nullptr;
   int64_t len1 = 0;
@@ -118,7 +124,7 @@ struct psa_batch {
     int cls_c0[psa::kEnumClasses + 1] = {};  // chunks of kernel class k: [cls_c0[k + 1], cls_c0[k]) (classes fall)
     psa::WaveParams wave{};
     // start and end of the candidate loop, one pair per slab (a one-pass batch alternates slabs)
-    hipEvent_t ev_b[2] = {nullptr, nullptr}, ev_e[2] = {nullptr, nullptr};
+    hipEvent_t ev_b[kMaxSlabs] = {}, ev_e[kMaxSlabs] = {};
     int last_buf = 0;
   };
   std::vector<SlabPass> passes;
@@ -206,6 +212,7 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP_C(hipStreamCreateWithFlags(&c->st_res, hipStreamNonBlocking));
   PSA_HIP_C(hipStreamCreateWithFlags(&c->st_pre, hipStreamNonBlocking));
   if (const char *e = std::getenv("PSA_ENUM_STREAMS")) c->enum_streams = std::atoi(e) == 1 ? 1 : 2;  // tuning aid
+  if (const char *e = std::getenv("PSA_SLABS")) c->nslabs = std::atoi(e) == 2 ? 2 : kMaxSlabs;          // tuning aid
   for (hipEvent_t &e : c->ev_prep) PSA_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP_C(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP_C(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
@@ -323,7 +330,7 @@ void psa_batch_destroy(psa_batch *b) {
     live.erase(std::remove(live.begin(), live.end(), b), live.end());
     (void)hipSetDevice(b->ctx->device);
     if (b->pending) (void)hipDeviceSynchronize();  // a run nobody waited for
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kMaxSlabs; ++i)
       if (b->ctx->slab_reader_batch[i] == b) {
         (void)hipEventSynchronize(b->ctx->slab_reader[i]);
         b->ctx->slab_reader[i] = nullptr;
@@ -457,7 +464,10 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     // or 32 x 32 tiles at ~46 on the matrix cores (8 per block of 32 q beyond the level's own 256, 36 inside)
     const int64_t unit_cycles = mfma_loop ? ((int64_t)std::max(0, 2 * runs_of(d.len2) - 8) * 8 + 36) * 46
                                           : (int64_t)std::max(1, runs_of(d.len2) - RW) * RW * 333;
-    int64_t ns = std::min<int64_t>(std::max<int64_t>(1, (72000 + unit_cycles / 2) / unit_cycles), ns_cap);
+    // (the matrix-core loop gains 2 to 3 % from units of about half a millisecond: one long pair of
+    // 8000 x 200000 runs 16 offsets per unit at 4.92e13 candidates/s against 4.76e13 with one)
+    const int64_t target_cycles = mfma_loop ? 1000000 : 72000;
+    int64_t ns = std::min<int64_t>(std::max<int64_t>(1, (target_cycles + unit_cycles / 2) / unit_cycles), ns_cap);
     if (const char *e = std::getenv("PSA_ENUM_NS")) ns = std::atoi(e);  // tuning aid
     d.enum_ns = (int32_t)std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
     min_ns = std::min(min_ns, d.enum_ns);
@@ -496,7 +506,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     if (!b->passes.empty()) b->passes.back().c1 = (int)chunks.size();
     bool two_slabs = b->passes.size() > 1;
     for (size_t k = 0; k < b->passes.size(); ++k) {
-      b->passes[k].buf = (int)(k & 1);
+      b->passes[k].buf = (int)(k % (size_t)c->nslabs);
     }
     b->two_slabs = two_slabs;
   }
@@ -548,12 +558,12 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   b->nchunks = (int)chunks.size();
   if (b->nchunks > 0) {
     // slabs of the context: grown when this batch needs more, two once a batch needs two passes
-    const int want = 2;
+    const int want = c->nslabs;
     if (cap_units > c->slab_units || want > c->slab_count) {
       const size_t units = std::max(cap_units, c->slab_units);
       const int count = std::max(want, c->slab_count);
       (void)hipDeviceSynchronize();  // runs enqueued on other batches may still use the old slabs
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < kMaxSlabs; ++i) {
         if (c->d_slab[i]) (void)hipFree(c->d_slab[i]);
         c->d_slab[i] = nullptr;
       }
@@ -631,7 +641,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     }
     for (hipEvent_t &e : u->ev)
       if (!e) PSA_HIP_B(hipEventCreate(&e));
-    while (u->pass_ev.size() < 4 * b->passes.size()) {
+    while (u->pass_ev.size() < 2 * kMaxSlabs * b->passes.size()) {
       hipEvent_t e = nullptr;
       PSA_HIP_B(hipEventCreate(&e));
       u->pass_ev.push_back(e);
@@ -666,9 +676,9 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     b->ev_tail[0] = u->ev[6];
     b->ev_tail[1] = u->ev[7];
     for (size_t k = 0; k < b->passes.size(); ++k)
-      for (int i = 0; i < 2; ++i) {
-        b->passes[k].ev_b[i] = u->pass_ev[4 * k + (size_t)i];
-        b->passes[k].ev_e[i] = u->pass_ev[4 * k + 2 + (size_t)i];
+      for (int i = 0; i < kMaxSlabs; ++i) {
+        b->passes[k].ev_b[i] = u->pass_ev[2 * kMaxSlabs * k + (size_t)i];
+        b->passes[k].ev_e[i] = u->pass_ev[2 * kMaxSlabs * k + kMaxSlabs + (size_t)i];
       }
   }
 #undef PSA_HIP_B
@@ -747,7 +757,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       psa_batch::SlabPass &sp = b->passes[k];
       // a one-pass batch alternates between the slabs from run to run, so that the pre-pass of a
       // run enqueued behind another runs beside that one's candidate loop
-      const int buf = piped ? sp.buf : (c->slab_flip ^= 1);
+      const int buf = piped ? sp.buf : (c->slab_flip = (c->slab_flip + 1) % c->nslabs);
       if (c->slab_reader[buf]) PSA_HIP(hipStreamWaitEvent(c->st_pre, c->slab_reader[buf], 0));
       int last_cls = -1;
       for (int cls = 0; cls < psa::kEnumClasses; ++cls)
@@ -763,7 +773,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
         P.nchunks = c1 - c0;
         P.fg = c->d_slab[buf];
         PSA_HIP(psa::launch_enum_prep(cls, P, c->enum_f32, c->st_pre, ev_first,
-                                      cls == last_cls ? c->ev_prep[k & 1] : nullptr));
+                                      cls == last_cls ? c->ev_prep[buf] : nullptr));
         ev_first = nullptr;
       }
       es = c->enum_streams > 1 ? (c->enum_flip ^= 1) : 0;
@@ -771,7 +781,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // this run's copy of the accumulators was last used two runs ago, maybe on the other stream
       if (b->tail_recorded[par] && !last_loop[es] && b->tail_stream[par] != es)
         PSA_HIP(hipStreamWaitEvent(st_loop, b->ev_tail[par], 0));
-      PSA_HIP(hipStreamWaitEvent(st_loop, c->ev_prep[k & 1], 0));
+      PSA_HIP(hipStreamWaitEvent(st_loop, c->ev_prep[buf], 0));
       psa::WaveParams W = sp.wave;
       W.chunks = b->d_chunks + sp.c0;
       W.chunk_best = chunk_best + sp.c0;

@@ -383,17 +383,17 @@ __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int
 // same 1024 candidates on the vector ALU alone (measured: 5.2 against 6.5 cycles per 128 candidates).
 //
 // Operand layout of v_mfma_f32_32x32x16_bf16 (lane l, r = l & 31, h = l >> 5): A[row r][k = 8h + j]
-// and B[k = 8h + j][col r] for element j = 0..7; result register v of lane l is row
-// (v & 3) + 8 (v >> 2) + 4h, column r.  Columns are positions p (a lane keeps the running maximum of
-// its own p over the rows, i.e. over q), rows are positions q.  The lower 32 lanes supply k = 0..7,
-// the upper 32 lanes k = 8..15: f's pieces sit in the lower lanes of B (against ones in A), g's
-// pieces in the upper lanes of A (against ones in B), so both halves of the operand registers
-// carry data and neither operand needs a lane of zeros:
-//   B: lower lanes (f_hi|f_mid), (f_lo|0), 0, 0      upper lanes (1|1), (1|1), 0, 0
-//   A: lower lanes (1|1), (1|1), 0, 0                upper lanes (g_hi|g_mid), (g_lo|0), 0, 0
-// A register that holds the packed pieces of 64 consecutive values (lane = position) turns into
-// the operand registers of its two blocks of 32 with one v_permlane32_swap_b32 against a register
-// of ones: the swap exchanges the upper half of one register with the lower half of the other.
+// and B[k = 8h + j][col r] for element j = 0..7 (two per operand register); result register v of
+// lane l is row (v & 3) + 8 (v >> 2) + 4h, column r.  Columns are positions p (a lane keeps the
+// running maximum of its own p over the rows, i.e. over q), rows are positions q.  The lower 32
+// lanes supply k = 0..7, the upper 32 lanes k = 8..15, so the pieces of one value are spread over
+// both halves: its (hi | mid) pair in the lower lane of its row or column, its (lo | 0) pair in
+// the upper lane, in the same operand register; the other operand holds ones there:
+//   A: register 0 = (g_hi | g_mid) in lane r, (g_lo | 0) in lane r + 32;  register 1 = (1 | 1);  2, 3 = 0
+//   B: register 0 = (1 | 1);  register 1 = (f_hi | f_mid) in lane c, (f_lo | 0) in lane c + 32;  2, 3 = 0
+// Two registers that hold the (hi | mid) and the (lo | 0) pairs of 64 consecutive values (lane =
+// position) turn into the operand registers of the two blocks of 32 with one v_permlane32_swap_b32,
+// which exchanges the upper half of its first register with the lower half of its second.
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -416,10 +416,10 @@ __device__ __forceinline__ void mfma_build_b(const int (&f)[4], i32x4 (&B)[8]) {
   for (int r = 0; r < 4; ++r) {
     int p0, p1;
     split_bf16x3(f[r], p0, p1);
-    const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)kOnesBf16, false, false);
-    const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)p1, (unsigned)kOnesBf16, false, false);
-    B[2 * r] = i32x4{(int)s0[0], (int)s1[0], 0, 0};      // lower lanes: positions 64 r + 0..31
-    B[2 * r + 1] = i32x4{(int)s0[1], (int)s1[1], 0, 0};  // lower lanes: positions 64 r + 32..63
+    // [p0.low | p1.low] = positions 64 r + 0..31, [p0.high | p1.high] = positions 64 r + 32..63
+    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)p1, false, false);
+    B[2 * r] = i32x4{kOnesBf16, (int)sw[0], 0, 0};
+    B[2 * r + 1] = i32x4{kOnesBf16, (int)sw[1], 0, 0};
   }
 }
 
@@ -464,10 +464,9 @@ __device__ __forceinline__ void mfma_tiles(const i32x4 &a, const i32x4 (&B)[8], 
 __device__ __forceinline__ void mfma_build_a(int g, i32x4 &a0, i32x4 &a1) {
   int p0, p1;
   split_bf16x3(g, p0, p1);
-  const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)kOnesBf16, (unsigned)p0, false, false);
-  const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)kOnesBf16, (unsigned)p1, false, false);
-  a0 = i32x4{(int)s0[0], (int)s1[0], 0, 0};  // upper lanes: positions 0..31 of the 64
-  a1 = i32x4{(int)s0[1], (int)s1[1], 0, 0};  // upper lanes: positions 32..63
+  const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)p1, false, false);
+  a0 = i32x4{(int)sw[0], kOnesBf16, 0, 0};  // positions 0..31 of the 64
+  a1 = i32x4{(int)sw[1], kOnesBf16, 0, 0};  // positions 32..63
 }
 
 // The block of 32 q with index RB (0..7) inside the level's own 256 positions: every block of p
@@ -510,9 +509,7 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
   const int *__restrict__ G = fg + ((size_t)ch.fg_row + (size_t)r0 * (nruns + 1)) * 64;  // row of offset r0
   const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, -1, 0x00020000);
   // Register r of f holds run pc0 + r of p; past the last run it repeats that run (its maxima are dropped below).
-  int vb[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) vb[r] = 4 * (64 * min(pc0 + r, nruns - 1) + lane);
+  auto vb = [&](int r) { return 4 * (64 * min(pc0 + r, nruns - 1) + lane); };  // recomputed where used: no registers held
   // mask of a diagonal tile: result register v of this lane is row (v & 3) + 8 (v >> 2) + 4 (lane >> 5), column lane & 31
   f32x16 mask;
 #pragma unroll
@@ -524,7 +521,7 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
   int soff = 0;  // byte offset of the current row
   int fn[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
+  for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), soff + 4 * rowlen, 0);
   int tn = G[rowlen + qend];  // the constant of the next row
   // the first two steps of an offset's row of g are requested while the offset before is scored
   int gfirst0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), soff, 0);
@@ -541,7 +538,7 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     soff += 4 * rowlen;
     if (i + 1 < r1) {  // next offset's f values arrive while this one is scored
 #pragma unroll
-      for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb[r], soff + 4 * rowlen, 0);
+      for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), soff + 4 * rowlen, 0);
       tn = G[2 * rowlen + qend];
     }
     G += rowlen;
