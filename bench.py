@@ -197,22 +197,21 @@ def cpu_baseline(seq1, seq2, budget_s=12.0):
                       % (S, n1, t1, nm, cores, tm, L2, L1)}
 
 
-def measured_traffic(cfg, f_bytes):
+def measured_traffic(cfg):
     """Memory-side bytes per launch of the candidate-loop kernel as the TCC counters saw them in the
-    committed rocprofv3 run of this workload (profiles/r02_c2_pmc.json, else r01); None for workloads
-    not profiled.  Calibration (profiles/r01_fetch_size_calibration.txt): the kernel's scalar reads are
-    counted in full, its dword-per-lane reads (f of an offset: the next offset's row of g, f_bytes) at half."""
+    committed rocprofv3 run of this workload (profiles/r02_c2_pmc.json); None for workloads not
+    profiled.  The kernel reads its rows with one dword per lane, which FETCH_SIZE counts at half
+    (calibration: profiles/r01_fetch_size_calibration.txt), so traffic = 2 x FETCH_SIZE + WRITE_SIZE."""
     if cfg != "c2":
         return None, None
-    for name in ("r02_c2_pmc.json", "r01_c2_pmc.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
-        with open(path) as f:
-            kernels = json.load(f)["kernels"]
-        for kname, c in kernels.items():
-            if "psa_enum_wave" in kname and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 + 0.5 * f_bytes, "profiles/" + name
+    path = os.path.join(ROOT, "profiles", "r02_c2_pmc.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        kernels = json.load(f)["kernels"]
+    for kname, c in kernels.items():
+        if "psa_enum_wave_mfma<false>" in kname and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "profiles/r02_c2_pmc.json"
     return None, None
 
 
@@ -443,6 +442,11 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
     return out
 
 
+def mfma_loop():
+    """The candidate loop runs on the matrix cores (float32 arithmetic, not switched off)."""
+    return os.environ.get("PSA_ENUM_I32", "0") in ("", "0") and os.environ.get("PSA_ENUM_MFMA", "1") != "0"
+
+
 def roofline_block(cfg, w):
     """Roofline of the candidate-loop kernel for this rank's share of the workload."""
     steps, cand_rank = w["steps"], w["cand_rank"]
@@ -455,15 +459,15 @@ def roofline_block(cfg, w):
     else:
         offsets = [float(w["shard"][1] - w["shard"][0])]
     slab_bytes = sum(4.0 * len(s2) * n for s2, n in zip(w["my_seq2"], offsets))
-    traffic, traffic_src = measured_traffic(cfg, slab_bytes)
+    traffic, traffic_src = measured_traffic(cfg) if mfma_loop() else (None, None)
     my_elapsed = w["per_rank"][0][0]
     lane_op_frac = cand_rank * OPS_PER_CANDIDATE / kern_s / PEAK_INT32_LANE_OPS
-    mfma = os.environ.get("PSA_ENUM_I32", "0") in ("", "0") and os.environ.get("PSA_ENUM_MFMA", "1") != "0"
+    mfma = mfma_loop()
     common = {
         "traffic": traffic,
-        "traffic_unit": "bytes per launch from the committed rocprofv3 --pmc passes of this command (%s: FETCH_SIZE + "
-                        "WRITE_SIZE, plus the half of the per-lane row reads that FETCH_SIZE does not count; "
-                        "Infinity-Cache hits included); a constant read from that file, not measured by this run"
+        "traffic_unit": "bytes per launch from the committed rocprofv3 --pmc passes of this command (%s: 2 x FETCH_SIZE, "
+                        "which counts the kernel's dword-per-lane reads at half, + WRITE_SIZE; reads served by the "
+                        "Infinity Cache included); a constant read from that file, not measured by this run"
                         % traffic_src if traffic is not None else None,
         "kernel_ms": kern_s * 1e3,
         # the same launch inside the timed region, where it shares the GPU with the launch

@@ -92,6 +92,7 @@ struct psa_ctx {
   unsigned char *d_seq1 = nullptr;
   int64_t len1 = 0;
   float table[PSA_TABLE_SIZE];
+  psa::FracScan frac_scan;  // of the table: the fixed-point scale per Seq2 follows from it and the length
   bool have_table = false, have_seq1 = false;
   float *d_table_t = nullptr;          // [27][32] floats, [seq2 code][seq1 code]
   unsigned char *d_class_t = nullptr;  // [27][32] class digits
@@ -216,8 +217,8 @@ int psa_init(int device, psa_ctx **out) {
   for (hipEvent_t &e : c->ev_prep) PSA_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP_C(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP_C(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
-  PSA_HIP_C(hipMalloc((void **)&c->d_probe, 3 * sizeof(unsigned long long)));
-  PSA_HIP_C(hipMemset(c->d_probe, 0, 3 * sizeof(unsigned long long)));
+  PSA_HIP_C(hipMalloc((void **)&c->d_probe, 64 * 8 * sizeof(unsigned long long)));
+  PSA_HIP_C(hipMemset(c->d_probe, 0, 64 * 8 * sizeof(unsigned long long)));
   std::vector<unsigned char> cls(psa::kDevTable, 3);
   for (int b = 0; b < 26; ++b)
     for (int a = 0; a < 26; ++a) cls[b * psa::kRowStride + a] = (unsigned char)psa::residue_class_code(a, b);
@@ -292,6 +293,7 @@ int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
     return PSA_ERR_STATE;
   }
   std::memcpy(c->table, table, sizeof c->table);
+  psa::frac_table_scan(c->table, &c->frac_scan);
   // device copy: transposed to [seq2 code][seq1 code], zero row and column for the padding code
   std::vector<float> t(psa::kDevTable, 0.0f);
   for (int a = 0; a < 26; ++a)
@@ -307,9 +309,11 @@ int psa_clock_probe(psa_ctx *c, int enable, double *clock_mhz, double *wave_cycl
   if (!c) return PSA_ERR_ARG;
   PSA_HIP(hipSetDevice(c->device));
   PSA_HIP(hipDeviceSynchronize());
-  unsigned long long v[3] = {0, 0, 0};
-  PSA_HIP(hipMemcpy(v, c->d_probe, sizeof v, hipMemcpyDeviceToHost));
-  PSA_HIP(hipMemset(c->d_probe, 0, sizeof v));
+  unsigned long long slots[64 * 8], v[3] = {0, 0, 0};
+  PSA_HIP(hipMemcpy(slots, c->d_probe, sizeof slots, hipMemcpyDeviceToHost));
+  PSA_HIP(hipMemset(c->d_probe, 0, sizeof slots));
+  for (int i = 0; i < 64; ++i)
+    for (int k = 0; k < 3; ++k) v[k] += slots[8 * i + k];
   if (clock_mhz) *clock_mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;
   if (wave_cycles_per_unit) *wave_cycles_per_unit = v[2] ? (double)v[0] / (double)v[2] : 0.0;
   c->probe_on = enable != 0;
@@ -347,8 +351,10 @@ void psa_batch_destroy(psa_batch *b) {
   delete b;
 }
 
+// stages: the stages the batch will ever run, if the caller knows (the one-shot entry points do);
+// a batch that never enumerates gets no chunk list, no per-chunk keys and no slabs
 static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, bool ranged, int64_t rb,
-                       int64_t re, psa_batch **out) {
+                       int64_t re, uint32_t stages, psa_batch **out) {
   if (!out) return PSA_ERR_ARG;
   *out = nullptr;
   if (!c || n < 0 || (n > 0 && !seq2)) return PSA_ERR_ARG;
@@ -414,7 +420,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     d.fs_base = fs_total;
     fs_total += se - sb;
     int exact = -1;
-    d.frac_bits = psa::choose_frac_bits(c->table, L2, c->enum_f32 ? psa::kSumBitsF32 : psa::kSumBitsI32, &exact);
+    d.frac_bits = psa::choose_frac_bits(c->frac_scan, L2, c->enum_f32 ? psa::kSumBitsF32 : psa::kSumBitsI32, &exact);
     if (psa::enum_class_of((int)L2) < 0) d.frac_bits = -1;
     r.enum_frac_bits = d.frac_bits;
     r.enum_exact = d.frac_bits >= 0 ? exact : -1;
@@ -429,7 +435,7 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   // Enumeration chunks, longest Seq2 first.  A wave of psa_enum_wave scores enum_ns
   // offsets x 256 positions p; a chunk (the pre-pass unit) is 2^sub_log2 such sub-runs.
   std::vector<int> order;
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n && (stages & PSA_STAGE_ENUMERATE); ++i)
     if (b->tmpl[(size_t)i].status == PSA_OK && b->desc[(size_t)i].frac_bits >= 0) order.push_back(i);
   std::stable_sort(order.begin(), order.end(),
                    [&](int x, int y) { return b->desc[(size_t)x].len2 > b->desc[(size_t)y].len2; });
@@ -687,14 +693,14 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
 }
 
 int psa_batch_create(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, psa_batch **out) {
-  return batch_build(c, n, seq2, len2, false, 0, 0, out);
+  return batch_build(c, n, seq2, len2, false, 0, 0, PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE, out);
 }
 
 int psa_batch_create_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end,
                            psa_batch **out) {
   const char *one[1] = {seq2};
   int32_t l[1] = {len2};
-  return batch_build(c, 1, one, len2 >= 0 ? l : nullptr, true, s_begin, s_end, out);
+  return batch_build(c, 1, one, len2 >= 0 ? l : nullptr, true, s_begin, s_end, PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE, out);
 }
 
 int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
@@ -974,7 +980,8 @@ int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms)
 int psa_score_batch(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, uint32_t stages,
                     psa_result *out) {
   psa_batch *b = nullptr;
-  int st = psa_batch_create(c, n, seq2, len2, &b);
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  int st = batch_build(c, n, seq2, len2, false, 0, 0, stages, &b);
   if (st != PSA_OK) return st;
   st = psa_batch_run(b, stages);
   if (st == PSA_OK) st = psa_batch_results(b, out);
@@ -985,7 +992,10 @@ int psa_score_batch(psa_ctx *c, int n, const char *const *seq2, const int32_t *l
 int psa_score_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end, uint32_t stages,
                     psa_result *out) {
   psa_batch *b = nullptr;
-  int st = psa_batch_create_range(c, seq2, len2, s_begin, s_end, &b);
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  const char *one[1] = {seq2};
+  int32_t l[1] = {len2};
+  int st = batch_build(c, 1, one, len2 >= 0 ? l : nullptr, true, s_begin, s_end, stages, &b);
   if (st != PSA_OK) return st;
   st = psa_batch_run(b, stages);
   if (st == PSA_OK) st = psa_batch_results(b, out);

@@ -603,9 +603,12 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     stamp_c = __builtin_amdgcn_s_memtime() - stamp_c;
     stamp_r = __builtin_amdgcn_s_memrealtime() - stamp_r;
     if (lane == 0) {
-      atomicAdd(&P.clock_probe[0], stamp_c);
-      atomicAdd(&P.clock_probe[1], stamp_r);
-      atomicAdd(&P.clock_probe[2], 1ull);
+      // 64 sets of counters, one 64-byte line each: thousands of waves adding to one address queue up
+      // behind each other and the kernel no longer runs at the pace (and clock) it is measured for
+      unsigned long long *slot = P.clock_probe + 8 * (u & 63);
+      atomicAdd(&slot[0], stamp_c);
+      atomicAdd(&slot[1], stamp_r);
+      atomicAdd(&slot[2], 1ull);
     }
   }
 }

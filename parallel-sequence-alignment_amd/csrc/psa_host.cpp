@@ -68,42 +68,56 @@ void build_table_from_weights(const float w[4], float out[PSA_TABLE_SIZE]) {
 // sum or difference of two prefix sums) below 2^(sum_bits + 1).  sum_bits = 29 keeps f, g
 // and f + g inside int32; sum_bits = 23 keeps them integers of at most 24 bits, which
 // float32 holds and adds exactly.
-int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int sum_bits, int *exact_level) {
-  const int64_t limit = (int64_t(1) << sum_bits) - 1;
-  int r = 24;
-  for (; r >= 0; --r) {
+// What the choice needs to know about a table, per candidate scale r: computed once per table
+// (676 roundings per scale), so that the choice per Seq2 is a loop over 25 numbers.
+void frac_table_scan(const float table[PSA_TABLE_SIZE], FracScan *fs) {
+  for (int r = 0; r <= 24; ++r) {
     int64_t mx = 0;
-    bool ok = true;
+    bool ok = true, exact = true;
+    int min_tz = 63;
     for (int i = 0; i < PSA_TABLE_SIZE && ok; ++i) {
       double v = std::nearbyint(std::ldexp(double(table[i]), r));
-      if (!(std::fabs(v) < 4e18)) ok = false;
-      else mx = std::max<int64_t>(mx, std::llabs((long long)v));
+      if (!(std::fabs(v) < 4e18)) {
+        ok = false;
+        break;
+      }
+      if (std::ldexp(v, -r) != double(table[i])) exact = false;
+      const int64_t iv = std::llabs((long long)v);
+      mx = std::max<int64_t>(mx, iv);
+      if (iv) min_tz = std::min(min_tz, __builtin_ctzll((unsigned long long)iv));
     }
-    if (ok && mx <= limit / std::max<int64_t>(len2, 1)) break;
+    fs->ok[r] = ok;
+    fs->mx[r] = mx;
+    fs->exact[r] = ok && exact;
+    fs->min_tz[r] = min_tz;
   }
+}
+
+int choose_frac_bits(const FracScan &fs, int64_t len2, int sum_bits, int *exact_level) {
+  const int64_t limit = (int64_t(1) << sum_bits) - 1;
+  int r = 24;
+  for (; r >= 0; --r)
+    if (fs.ok[r] && fs.mx[r] <= limit / std::max<int64_t>(len2, 1)) break;
   if (r < 0) {
     *exact_level = -1;
     return -1;
   }
   // exactness: 1 if every entry is k * 2^-r, 2 if moreover all partial sums of up
   // to len2 entries fit the 24-bit significand of float32 at the coarsest such scale
-  bool table_exact = true;
-  int64_t mx = 0;
-  int min_tz = 63;
-  for (int i = 0; i < PSA_TABLE_SIZE; ++i) {
-    double v = std::nearbyint(std::ldexp(double(table[i]), r));
-    if (std::ldexp(v, -r) != double(table[i])) table_exact = false;
-    int64_t iv = std::llabs((long long)v);
-    mx = std::max(mx, iv);
-    if (iv) min_tz = std::min(min_tz, __builtin_ctzll((unsigned long long)iv));
-  }
   *exact_level = 0;
-  if (table_exact) {
+  if (fs.exact[r]) {
     *exact_level = 1;
-    int shift = mx == 0 ? 0 : std::min(min_tz, r);
+    const int64_t mx = fs.mx[r];
+    const int shift = mx == 0 ? 0 : std::min(fs.min_tz[r], r);
     if ((mx >> shift) * len2 < (int64_t(1) << 24)) *exact_level = 2;
   }
   return r;
+}
+
+int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int sum_bits, int *exact_level) {
+  FracScan fs;
+  frac_table_scan(table, &fs);
+  return choose_frac_bits(fs, len2, sum_bits, exact_level);
 }
 
 // Row n of the mutant triangle starts at 1-based number (n-1)*L - n(n-1)/2 + 1.

@@ -64,6 +64,15 @@ void build_table_from_weights(const float w[4], float out[PSA_TABLE_SIZE]);
 constexpr int kSumBitsI32 = 29;  // prefix-sum width of the enumeration stage in int32 arithmetic
 constexpr int kSumBitsF32 = 23;  // and in float32 arithmetic (integers of at most 24 bits)
 int choose_frac_bits(const float table[PSA_TABLE_SIZE], int64_t len2, int sum_bits, int *exact_level);
+// the same in two steps: a scan of the table per candidate scale (once per table), then the choice per Seq2
+struct FracScan {
+  bool ok[25];         // every entry times 2^r rounds to a representable integer
+  bool exact[25];      // ... and equals the entry exactly
+  int64_t mx[25];      // largest |round(entry * 2^r)|
+  int min_tz[25];      // fewest trailing zero bits among the non-zero rounded entries
+};
+void frac_table_scan(const float table[PSA_TABLE_SIZE], FracScan *fs);
+int choose_frac_bits(const FracScan &fs, int64_t len2, int sum_bits, int *exact_level);
 void nk_of_mutant(int64_t t, int len2, int *n, int *k);
 int64_t mutant_of_nk(int n, int k, int len2);
 double cost_estimate(int64_t len2, int64_t len1, uint32_t stages);

@@ -39,7 +39,8 @@ struct WaveParams {
   int sub_log2;                            // sub-runs per chunk = 1 << sub_log2
   int level_base[kEnumMaxLevels + 1];      // first unit of each level; unused entries hold INT_MAX
   int nunits;
-  // diagnostic (null in normal runs): [0] += shader cycles, [1] += 100 MHz ticks, [2] += 1 per unit
+  // diagnostic (null in normal runs): 64 slots of 8 words; a unit adds to slot (unit & 63):
+  // [0] += shader cycles, [1] += 100 MHz ticks, [2] += 1
   unsigned long long *clock_probe;
 };
 

@@ -16,7 +16,7 @@ for pmc in "$@"; do
   echo "pmc pass $i done"
 done
 cd $GRAFT_REPO_ROOT
-python3 tools/pmc_summary.py $dirs > $out/${tag}_pmc.json || exit 1
+python3 tools/pmc_summary.py --command "rocprofv3 --pmc <one counter list per run> --output-format csv -- python3 bench.py --no-cpu-baseline --no-scale --no-host-inclusive $bargs; counter lists: $*" --workload "$bargs" $dirs > $out/${tag}_pmc.json || exit 1
 python3 - $out/${tag}_pmc.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
