@@ -128,7 +128,11 @@ int psa_batch_run(psa_batch *b, uint32_t stages);
  * Runs enqueued back to back (on this batch or on other batches of the context) execute in
  * order, so a caller that streams many batches keeps the GPU busy while it prepares the next
  * one -- the per-Seq2 blocking call of the reference (P/main.c:81, :130) has no such overlap.
- * A batch holds one set of records: enqueueing it again before wait overwrites them. */
+ * A batch holds one set of records: enqueueing it again before wait overwrites them.
+ * Wait for results with psa_batch_wait (the host waits for an event), not by making a stream of
+ * your own wait on the library's work: the library's streams all have the default priority, and
+ * a wait in a higher-priority queue on a dispatch that sits in a lower-priority queue is never
+ * satisfied on this hardware (the higher queue is served first, barrier packet and all). */
 int psa_batch_enqueue(psa_batch *b, uint32_t stages);
 int psa_batch_wait(psa_batch *b);
 /* copies the n records of the last run */
