@@ -657,6 +657,31 @@ def test_stream_of_batches(psa, oracle):
     c.close()
 
 
+def test_clock_probe_variant(psa, oracle):
+    """The stamped variant of the candidate loop returns the same records as the plain one, and the
+    clock it reports is a shader clock this chip can hold."""
+    seq1, seq2s = synth_problem(94, 3000, [2000, 700, 1300, 64])
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    b = c.batch(seq2s)
+    b.run()
+    plain = [r.key() + r.enum_key() + tuple(r.enum_counts) for r in b.results()]
+    assert c.clock_probe(True) == (0.0, 0.0)       # nothing ran with the probe on yet
+    for _ in range(20):
+        b.run()
+    stamped = [r.key() + r.enum_key() + tuple(r.enum_counts) for r in b.results()]
+    mhz, cycles = c.clock_probe(False)
+    assert stamped == plain
+    assert 500.0 < mhz < 2500.0 and cycles > 0
+    b.run()
+    assert c.clock_probe(False) == (0.0, 0.0)      # probe off: the counters stay clear
+    assert [r.key() + r.enum_key() + tuple(r.enum_counts) for r in b.results()] == plain
+    b.close()
+    c.close()
+
+
 def test_long_seq2(psa, ctx, oracle):
     """Seq2 of 4095/4096/8000/8191 characters: the two largest kernel variants."""
     seq1, seq2s = synth_problem(77, 9000, [4095, 4096, 8000, 8191])

@@ -78,6 +78,22 @@ def test_partition_balances_cost(psa):
     assert psa.cost_estimate(700, L1, psa.STAGE_RESOLVE) == (L1 - 700 + 3) * 700.0
 
 
+def test_bench_tile_count_matches_cost_model(psa):
+    """The tile count bench.py prices the candidate loop with is the one the library's cost model uses."""
+    import importlib.util, pathlib
+    spec = importlib.util.spec_from_file_location("bench_mod", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    L1 = 9000
+    for L2 in (2, 31, 32, 33, 64, 65, 255, 256, 257, 500, 1000, 2000, 4097, 8191):
+        S = L1 - L2 + 3
+        levels = (64 * ((L2 + 63) // 64) + 255) // 256
+        tiles = (psa.cost_estimate(L2, L1, 0) / S - 300.0 * levels) / 45.0
+        assert tiles == bench.tiles_per_offset(L2), L2
+        # every candidate pair (p < q) lies in a counted tile
+        assert bench.tiles_per_offset(L2) * 1024 >= L2 * (L2 - 1) // 2
+
+
 def test_combine_results_tie_order(psa):
     def rec(score, n, k, off, cand=10):
         r = psa.Result()
