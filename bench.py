@@ -233,7 +233,7 @@ class Job:
             raise SystemExit("bench.py needs a GPU (no CPU fallback)")
         torch.cuda.set_device(self.local_rank)
         self.dist = None
-        if self.world > 1:
+        if self.world > 1 or args.force_dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if args.backend == "nccl":
@@ -581,6 +581,9 @@ def main():
     ap.add_argument("--no-scale", action="store_true", help="skip the scale block (c3 and c4) of the default run")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="wait for every step before launching the next")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group even for one rank (under torch.distributed.run): runs the "
+                         "broadcast, gathers and the long pair's all-gather through the backend on a one-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
