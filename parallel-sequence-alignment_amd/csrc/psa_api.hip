@@ -57,6 +57,7 @@ void bundle_free(Bundle *u) {
 }
 
 constexpr size_t kMaxCachedBundles = 4;
+constexpr size_t kSmallUpload = 64u << 10;  // work lists up to this size are fetched by the first run's set-up kernel
 constexpr int kMaxSlabs = 3;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -161,6 +162,9 @@ struct psa_batch {
   bool acc_ready = false;  // the accumulators were reset after the previous run
   Bundle *res = nullptr;   // owns every device and pinned pointer above and the events
   bool upload_in_flight = false;  // the asynchronous upload of the work lists has not been waited for
+  // small batches: the work lists stay in the pinned block and the first run's set-up kernel copies them
+  const unsigned char *setup_src = nullptr;
+  size_t setup_bytes = 0;
 };
 
 extern "C" {
@@ -658,10 +662,17 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     if (!b->desc.empty()) std::memcpy(u->pin + o_desc, b->desc.data(), b->desc.size() * sizeof(psa::SeqDesc));
     if (!fwd.empty()) std::memcpy(u->pin + o_fwd, fwd.data(), fwd.size() * sizeof(psa::FwdBlock));
     if (!chunks.empty()) std::memcpy(u->pin + o_chunks, chunks.data(), chunks.size() * sizeof(psa::Chunk));
-    PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_pre));
-    PSA_HIP_B(hipEventRecord(u->ev[5], c->st_pre));
-    b->ev_upload = u->ev[5];
-    b->upload_in_flight = true;
+    if (upload_bytes <= kSmallUpload) {
+      // a few KB: the first run's set-up kernel reads them through the mapping of the pinned block
+      // (one launch on the resolve stream instead of a copy, an event, a memset and a kernel)
+      b->setup_src = u->pin_dev;
+      b->setup_bytes = upload_bytes;
+    } else {
+      PSA_HIP_B(hipMemcpyAsync(u->dev, u->pin, upload_bytes, hipMemcpyHostToDevice, c->st_pre));
+      PSA_HIP_B(hipEventRecord(u->ev[5], c->st_pre));
+      b->ev_upload = u->ev[5];
+      b->upload_in_flight = true;
+    }
     b->d_pool = u->dev + o_pool;
     b->d_desc = (psa::SeqDesc *)(u->dev + o_desc);
     b->d_fwd = (psa::FwdBlock *)(u->dev + o_fwd);
@@ -718,11 +729,17 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   const bool init = !b->acc_ready;
   if (init) {
     // on st_res, which never waits for a candidate loop
-    if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_upload, 0));
-    PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 1, c->st_res));
-    PSA_HIP(psa::debug_sync("psa_init_acc"));
-    if (b->nchunks > 0)
-      PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, 2 * (size_t)b->nchunks * sizeof(unsigned long long), c->st_res));
+    if (b->setup_src) {
+      PSA_HIP(psa::launch_setup_small(b->setup_src, b->d_pool, b->setup_bytes, b->d_acc, 2 * b->n, b->d_counters, 1,
+                                      b->d_chunk_best, 2 * (size_t)b->nchunks, c->st_res));
+      PSA_HIP(psa::debug_sync("psa_setup_small"));
+    } else {
+      if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_upload, 0));
+      PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 1, c->st_res));
+      PSA_HIP(psa::debug_sync("psa_init_acc"));
+      if (b->nchunks > 0)
+        PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, 2 * (size_t)b->nchunks * sizeof(unsigned long long), c->st_res));
+    }
     PSA_HIP(hipEventRecord(b->ev_init, c->st_res));
     PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
     for (hipStream_t st : c->st_enum) PSA_HIP(hipStreamWaitEvent(st, b->ev_init, 0));
@@ -861,6 +878,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.nactive = b->d_counters;
     P.pchunks = (b->max_len2 + 255) / 256;
     int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
+    if (const char *e = std::getenv("PSA_TIE_GRID")) tie_grid = std::max(1, std::min(8192, std::atoi(e)));  // tuning aid
     PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res, b->ev_res_first));
   }
   if (resolve || !enumerate) {

@@ -81,6 +81,10 @@ hipError_t debug_sync(const char *what);
 hipError_t set_enum_kernel_attributes();
 hipError_t set_resolve_kernel_attributes();
 hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hipStream_t st);
+// set-up of a small batch in one launch: copy of the staged work lists (src: device mapping of pinned
+// host memory; bytes rounded up to 16 must lie inside both blocks) + what launch_init does + cleared chunk keys
+hipError_t launch_setup_small(const void *src, void *dst, size_t bytes, SeqAcc *acc, int nacc, unsigned *counters,
+                              int ncounters, unsigned long long *best, size_t nbest, hipStream_t st);
 // ev_start / ev_stop (may be null) are attached to the kernel's dispatch, not recorded beside it
 // f32: the slab holds float32 values and the candidate loop adds and compares in float32
 // (exact: the scale keeps every value an integer of at most 24 bits); otherwise int32

@@ -8,6 +8,7 @@
 // the first maximiser in (n, k, offset) order -- the reference's strict '>' rule
 // (S/main.c:74, P/cudaFunctions.cu:241, P/cFunctions.c:129,146) -- from two further
 // passes over the offsets that attain the maximum (psa_first_p, psa_first_q).
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -16,6 +17,16 @@
 #include "psa_device.h"
 
 namespace psa {
+
+// Built with -DPSA_TRACE the chain kernels print, per workgroup, the shader cycles between the
+// marks PSA_TS() in their code (s_memtime) -- where the microseconds of a latency-bound kernel go.
+#ifdef PSA_TRACE
+#define PSA_TS_DECL() unsigned long long ts_[12]; int nts_ = 0;
+#define PSA_TS() ts_[nts_++] = __builtin_amdgcn_s_memtime();
+#else
+#define PSA_TS_DECL()
+#define PSA_TS()
+#endif
 
 // ---------------------------------------------------------------------------------
 // per-batch initialisation of the accumulators and counters
@@ -36,20 +47,27 @@ __global__ void psa_init_acc(SeqAcc *acc, int n, unsigned *counters, int ncounte
 
 // ---------------------------------------------------------------------------------
 // float32 resolve, pass 1: per-offset maximum over all (n,k); lanes = offsets.
-// State before Seq2 position j: a (no deletion yet), b (one), c (two).
+// State of offset s before Seq2 position j: a (no deletion yet), b (one), c (two).
 //   a' = a + x0,  b' = max(a, b + x1),  c' = max(b, c + x2),   x_d = T[A[s+j-d]][B[j]]
 // (delete j, or keep it after d deletions).  Rounding is monotone, so taking the max
 // before continuing the chain is exact.
 //
-// Consecutive lanes hold consecutive offsets, so x1 of lane l is x0 of lane l - 1 and x2
-// is x0 of lane l - 2 at the same step: one LDS table read per lane and step, the other
-// two entries arrive through wave-wide lane shifts (DPP wave_shr:1).  Lanes 0 and 1 of a
-// wave have no left neighbours; they run the two offsets below the wave's first and are
-// not used, so a wave yields 62 offsets and a block kFwdOffsets = 248.
+// x1 of offset s is x0 of offset s - 1 and x2 is x0 of offset s - 2 at the same step, so a lane
+// keeps the three states of three CONSECUTIVE offsets that meet the same table entry: lane l
+// of a wave reads x0 of offset u = base + l and holds a of u, b of u + 1 and c of u + 2.  Then
+//   a_u += x0,  b_{u+1} = max(a_{u+1}, b_{u+1} + x0),  c_{u+2} = max(b_{u+2}, c_{u+2} + x0),
+// where a_{u+1} and b_{u+2} are the values the next lane holds: they arrive as the shifted
+// operand of the max itself (DPP wave_shl:1), b and c advance with one packed add.  A step is
+// one LDS table read, its address add and four vector instructions.  The last two lanes of a
+// wave have no complete right neighbours, so a wave yields 62 offsets and a block
+// kFwdOffsets = 248.
 // The kernel runs one wave per SIMD and is bound by how fast that wave can issue, i.e.
 // by instructions per step: the Seq1 codes and the Seq2 row offsets of a group of four
 // steps are fetched two groups ahead, the table entries one group ahead, so no LDS
 // latency sits on the dependent chain.
+// (This file is compiled with -fno-honor-nans: no NaN can arise here -- finite table entries,
+// and -inf only ever meets finite values -- and without the flag every max would first
+// canonicalise its operands, one more instruction on the chain each.)
 //
 // LDS: table | row byte offsets of Seq2 (128 * code per position) | Seq1 window as byte
 // offsets (4 * code)
@@ -57,16 +75,11 @@ __global__ void psa_init_acc(SeqAcc *acc, int n, unsigned *counters, int ncounte
 __host__ __device__ inline int fwd_rows(int len2) { return ((len2 + 3) / 4) * 4 + 16; }
 __host__ __device__ inline int fwd_window(int len2) { return kFwdOffsets + 2 + len2 + 16; }
 
-__device__ __forceinline__ float lane_shr1(float v) {
-  // lane l receives lane l - 1's value; lane 0 receives 0
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-// max without the canonicalising self-max that fmaxf costs per operand (no NaN can occur here:
-// finite table entries, and -inf only ever meets finite values)
-__device__ __forceinline__ float max_f32(float x, float y) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-  return r;
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float lane_shl1(float v) {
+  // lane l receives lane l + 1's value; lane 63 receives 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 
@@ -74,6 +87,8 @@ __global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  PSA_TS_DECL()
+  PSA_TS()
   FwdBlock fb;
   fb.seq = uni(P.fwd_blocks[blockIdx.x].seq);
   fb.s0 = uni(P.fwd_blocks[blockIdx.x].s0);
@@ -82,35 +97,61 @@ __global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
   int *rowb = (int *)(smem + kDevTable * 4);        // fwd_rows(L2) ints, 16-byte aligned
   int *aw = rowb + fwd_rows(L2);                    // fwd_window(L2) byte offsets
   uint32_t *red = (uint32_t *)(aw + fwd_window(L2));
+  PSA_TS()
   for (int i = tid; i < kDevTable; i += 256) ((float *)smem)[i] = P.table_t[i];
+  // The residues come from global memory eight per thread at a time, all eight requested before
+  // the first is used: one memory round trip per 2048 positions instead of one per 256.
+  constexpr int B = 8;
   {
     // a row entry is the LDS address of the table row of that Seq2 residue, so that a table
     // entry's address is one add: row + 4 * (Seq1 code)
     const int tbase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const unsigned char *src = P.seq2_pool + d.off2;
-    for (int i = tid; i < fwd_rows(L2); i += 256)
-      rowb[i] = tbase + (i < L2 ? (int)src[i] : kPadCode) * (kRowStride * 4);
+    const int n = fwd_rows(L2);
+    for (int i0 = tid; i0 < n; i0 += 256 * B) {
+      int code[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) code[u] = src[min(i0 + 256 * u, L2 - 1)];
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < n) rowb[i] = tbase + (i < L2 ? code[u] : kPadCode) * (kRowStride * 4);
+      }
+    }
   }
-  const int win0 = fb.s0 - 2;  // Seq1 index of window entry 0
-  for (int i = tid; i < fwd_window(L2); i += 256) {
-    int64_t idx = (int64_t)win0 + i;
-    aw[i] = 4 * ((idx >= 0 && idx < P.len1) ? (int)P.seq1[idx] : kPadCode);
+  {
+    const int64_t win0 = (int64_t)fb.s0 - 2;  // Seq1 index of window entry 0
+    const int n = fwd_window(L2);
+    for (int i0 = tid; i0 < n; i0 += 256 * B) {
+      int code[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int64_t idx = win0 + i0 + 256 * u;
+        code[u] = P.seq1[idx < 0 ? 0 : (idx < P.len1 ? idx : P.len1 - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + 256 * u;
+        const int64_t idx = win0 + i;
+        if (i < n) aw[i] = 4 * ((idx >= 0 && idx < P.len1) ? code[u] : kPadCode);
+      }
+    }
   }
   __syncthreads();
-  const int s = fb.s0 + 62 * w + lane - 2;
-  const int *ap = aw + 62 * w + lane;  // ap[j] = 4 * code of Seq1[s + j]
+  PSA_TS()
+  const int s = fb.s0 + 62 * w + lane;  // the offset whose c this lane holds (its b: s - 1, its a: s - 2)
+  const int *ap = aw + 62 * w + lane;   // ap[j] = 4 * code of Seq1[s - 2 + j]
   const float NEG = -INFINITY;
-  float a = 0.0f, b = NEG, c = NEG;
+  float a = 0.0f;
+  f2 bc = {NEG, NEG};
 #define PSA_T(addr) (*(lds_cfloat *)(uintptr_t)(unsigned)(addr))
-#define PSA_STEP(x0)                        \
-  {                                         \
-    const float x1_ = lane_shr1(x0);        \
-    const float x2_ = lane_shr1(x1_);       \
-    const float nc_ = max_f32(b, c + x2_);  \
-    const float nb_ = max_f32(a, b + x1_);  \
-    a = a + (x0);                           \
-    b = nb_;                                \
-    c = nc_;                                \
+#define PSA_STEP(x0)                                             \
+  {                                                              \
+    const f2 t_ = bc + (f2){(x0), (x0)};                         \
+    const float nc_ = __builtin_fmaxf(lane_shl1(bc.x), t_.y);    \
+    const float nb_ = __builtin_fmaxf(lane_shl1(a), t_.x);       \
+    a = a + (x0);                                                \
+    bc = (f2){nb_, nc_};                                         \
   }
   // groups of four steps in which all three states advance: j + 3 <= L2 - 3.  Two groups per
   // iteration, so the table entries alternate between two register sets without copies.
@@ -154,18 +195,18 @@ __global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
   // remaining positions, one at a time
   for (int j = 4 * ngroups; j < L2; ++j) {
     const float x0 = PSA_T(rowb[j] + ap[j]);
-    const float x1 = lane_shr1(x0);
-    const float x2 = lane_shr1(x1);
-    const float nc = max_f32(b, c + x2);
-    const float nb = (j <= L2 - 2) ? max_f32(a, b + x1) : NEG;  // one deletion must still follow
-    if (j <= L2 - 3) a = a + x0;                                // two deletions must still follow
-    b = nb;
-    c = nc;
+    const f2 t = bc + (f2){x0, x0};
+    const float nc = __builtin_fmaxf(lane_shl1(bc.x), t.y);
+    const float nb = (j <= L2 - 2) ? __builtin_fmaxf(lane_shl1(a), t.x) : NEG;  // one deletion must still follow
+    if (j <= L2 - 3) a = a + x0;                                               // two deletions must still follow
+    bc = (f2){nb, nc};
   }
 #undef PSA_STEP
 #undef PSA_T
+  PSA_TS()
+  const float c = bc.y;
   uint32_t key = 0u;
-  if (lane >= 2 && s < d.s_end) {
+  if (lane < 62 && s < d.s_end) {
     P.fs[d.fs_base + (s - d.s_begin)] = c;
     key = f2key(c);
   }
@@ -180,6 +221,12 @@ __global__ __launch_bounds__(256) void psa_fwd(ResolveParams P) {
     for (int i = 1; i < 4; ++i) key = red[i] > key ? red[i] : key;
     atomicMax(&P.acc[fb.seq].res_key, key);
   }
+#ifdef PSA_TRACE
+  PSA_TS()
+  if (tid == 0 && blockIdx.x < 6)
+    printf("fwd blk %d L2 %d: desc %llu stage %llu chain %llu tail %llu\n", (int)blockIdx.x, L2, ts_[1] - ts_[0], ts_[2] - ts_[1],
+           ts_[3] - ts_[2], ts_[4] - ts_[3]);
+#endif
 }
 
 // pass 2: list the offsets whose maximum equals the Seq2's maximum
@@ -199,83 +246,132 @@ __global__ __launch_bounds__(256) void psa_collect(ResolveParams P) {
   }
 }
 
-// Table entries seen by Seq2 position j at offset s after 0, 1, 2 deletions.
 // ---------------------------------------------------------------------------------
 // passes 3 and 4 work on one offset that attains the maximum.  LDS holds the table
-// entries Seq2 position j meets there after 0 deletions (d0[j]) and after 1 and 2
-// deletions (d12[j] = {d1, d2}).  d12[L2-1].x is -inf: a chain with one deletion
-// cannot consume the last position.  d12 is padded with 256 + 8 zero pairs so that
-// lanes may run past the end: adding +0.0 changes nothing.
+// entries Seq2 position j meets there after 0 deletions (d0[j]) and after 2 and 1
+// deletions (d21[j] = {d2, d1}).  d21[L2-1].y is -inf: a chain with one deletion
+// cannot consume the last position.  Both arrays are padded with zeros (d21 with
+// 256 + kTiePad pairs) so that lanes and prefetches may run past the end: adding +0.0
+// changes no value.
 // ---------------------------------------------------------------------------------
-__host__ __device__ inline int tie_d0_len(int len2) { return ((len2 + 8 + 3) / 4) * 4; }
-__host__ __device__ inline int tie_d12_len(int len2) { return len2 + 256 + 8; }
+constexpr int kTiePad = 64;
+__host__ __device__ inline int tie_d0_len(int len2) { return ((len2 + kTiePad + 3) / 4) * 4; }
+__host__ __device__ inline int tie_d21_len(int len2) { return len2 + 256 + kTiePad; }
 
-__device__ __forceinline__ void fill_diagonals(float *d0, float2 *d12, const float *T, const ResolveParams &P,
+// The residues come from global memory eight per thread at a time, all requested before the first
+// is used (one memory round trip per 2048 positions), into two byte arrays in LDS behind d21: Seq2,
+// and the window of Seq1 that starts two positions before the offset; the table entries are then
+// looked up from LDS alone.  Ends with a barrier.
+__host__ __device__ inline int tie_codes_len(int len2) { return ((len2 + 2 + 15) / 16) * 16; }
+
+__device__ __forceinline__ void fill_diagonals(float *d0, f2 *d21, const float *T, const ResolveParams &P,
                                                const SeqDesc &d, int s) {
-  const int L2 = d.len2;
-  for (int j = threadIdx.x; j < tie_d12_len(L2); j += blockDim.x) {
-    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-    if (j < L2) {
-      const int b = P.seq2_pool[d.off2 + j];
-      const float *row = T + b * kRowStride;
-      const int64_t i0 = (int64_t)s + j;
-      const int c0 = (i0 < P.len1) ? P.seq1[i0] : kPadCode;
-      const int c1 = (i0 - 1 >= 0 && i0 - 1 < P.len1) ? P.seq1[i0 - 1] : kPadCode;
-      const int c2 = (i0 - 2 >= 0 && i0 - 2 < P.len1) ? P.seq1[i0 - 2] : kPadCode;
-      v0 = row[c0];
-      v1 = (j == L2 - 1) ? -INFINITY : row[c1];
-      v2 = row[c2];
+  const int L2 = d.len2, tid = threadIdx.x;
+  unsigned char *c2 = (unsigned char *)(d21 + tie_d21_len(L2));  // Seq2[j]
+  unsigned char *c1 = c2 + tie_codes_len(L2);                    // Seq1[s - 2 + i], i < L2 + 2
+  constexpr int B = 8;
+  const unsigned char *src2 = P.seq2_pool + d.off2;
+  for (int i0 = tid; i0 < L2 + 2; i0 += 256 * B) {
+    int a[B], b[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int i = i0 + 256 * u;
+      const int64_t idx = (int64_t)s - 2 + i;
+      b[u] = src2[min(i, L2 - 1)];
+      a[u] = P.seq1[idx < 0 ? 0 : (idx < P.len1 ? idx : P.len1 - 1)];
     }
-    if (j < tie_d0_len(L2)) d0[j] = v0;
-    d12[j] = make_float2(v1, v2);
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int i = i0 + 256 * u;
+      const int64_t idx = (int64_t)s - 2 + i;
+      if (i < L2) c2[i] = (unsigned char)b[u];
+      if (i < L2 + 2) c1[i] = (unsigned char)((idx >= 0 && idx < P.len1) ? a[u] : kPadCode);
+    }
   }
+  __syncthreads();
+  // (four positions per thread in flight: the three dependent LDS reads of a position are latency)
+  constexpr int U = 4;
+  for (int j0 = tid; j0 < tie_d21_len(L2); j0 += 256 * U) {
+    int cb[U], ca[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = min(j0 + 256 * u, L2 - 1);
+      cb[u] = c2[j];
+      ca[u][0] = c1[j + 2];
+      ca[u][1] = c1[j + 1];
+      ca[u][2] = c1[j];
+    }
+    float t[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float *row = T + cb[u] * kRowStride;
+      t[u][0] = row[ca[u][0]];
+      t[u][1] = row[ca[u][1]];
+      t[u][2] = row[ca[u][2]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + 256 * u;
+      if (j < tie_d21_len(L2)) {
+        const bool in = j < L2;
+        if (j < tie_d0_len(L2)) d0[j] = in ? t[u][0] : 0.0f;
+        d21[j] = (f2){in ? t[u][2] : 0.0f, in ? (j == L2 - 1 ? -INFINITY : t[u][1]) : 0.0f};
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // Serial float32 chains over LDS arrays.  The adds are dependent by nature (the reference's
-// rounding order); what can be hidden is the LDS latency: 8 values are in flight while
-// the previous 8 are added, and the loop is unrolled twice so no register is copied.
-
-// v += d0[from .. to), left to right (every lane computes the same value)
-__device__ __forceinline__ float add_run_d0(const float *d0, int from, int to, float v) {
+// rounding order) and a lone wave issues a dependent add every 10.5 cycles; what can be hidden
+// is the LDS latency: the next 16 values are requested before the current 16 are added (the
+// scheduling barriers keep the compiler from sinking the requests below the adds, or from
+// hoisting them into the adds, which costs a second set of registers and copies).
+//
+// v += src[STRIDE * j] for j in [from, to), left to right, every lane the same value.  With HAND
+// lane `my` stops before position `my`: it adds +0.0 from there on (which changes no value), so
+// that it ends with the value of the chain before position `my` -- the compare and the select
+// that zero an element do not depend on the chain, only the add does.
+// Reads up to 32 elements past `to` (the arrays are padded).
+template <int STRIDE, bool HAND>
+__device__ __forceinline__ float add_run(const float *src, int from, int to, float v, int my) {
+  int n = to - from;
+  if (n <= 0) return v;
   int j = from;
-  for (; j < to && (j & 3); ++j) v += d0[j];
-  if (j + 8 <= to) {
-    float4 a0 = *(const float4 *)(d0 + j), a1 = *(const float4 *)(d0 + j + 4);
-    for (; j + 24 <= to; j += 16) {
-      const float4 b0 = *(const float4 *)(d0 + j + 8), b1 = *(const float4 *)(d0 + j + 12);
-      v += a0.x; v += a0.y; v += a0.z; v += a0.w; v += a1.x; v += a1.y; v += a1.z; v += a1.w;
-      a0 = *(const float4 *)(d0 + j + 16);
-      a1 = *(const float4 *)(d0 + j + 20);
-      v += b0.x; v += b0.y; v += b0.z; v += b0.w; v += b1.x; v += b1.y; v += b1.z; v += b1.w;
-    }
-    v += a0.x; v += a0.y; v += a0.z; v += a0.w; v += a1.x; v += a1.y; v += a1.z; v += a1.w;
-    j += 8;
+  int rel = my - from;  // positions this lane still adds
+  float y[16], z[16];
+#define PSA_LOAD(r, j0)                                                  \
+  _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[STRIDE * ((j0) + k)];
+#define PSA_ADDS(r)                                                       \
+  _Pragma("unroll") for (int k = 0; k < 16; ++k) v += HAND ? (k < rel ? r[k] : 0.0f) : r[k]; \
+  rel -= 16;
+#define PSA_ADDS_PART(r, j0)                                              \
+  _Pragma("unroll") for (int k = 0; k < 16; ++k)                          \
+    if ((j0) + k < to) v += HAND ? (k < rel ? r[k] : 0.0f) : r[k];       \
+  rel -= 16;
+  PSA_LOAD(y, j)
+  while (n >= 32) {
+    PSA_LOAD(z, j + 16)
+    __builtin_amdgcn_sched_barrier(0);
+    PSA_ADDS(y)
+    __builtin_amdgcn_sched_barrier(0);
+    PSA_LOAD(y, j + 32)
+    __builtin_amdgcn_sched_barrier(0);
+    PSA_ADDS(z)
+    j += 32;
+    n -= 32;
   }
-  for (; j < to; ++j) v += d0[j];
-  return v;
-}
-
-// v += d12[from .. to).x, left to right (uniform)
-__device__ __forceinline__ float add_run_d1(const float2 *d12, int from, int to, float v) {
-  int j = from;
-  for (; j < to && (j & 1); ++j) v += d12[j].x;
-  if (j + 8 <= to) {
-    const float4 *q = (const float4 *)(d12 + j);  // two positions per 16-byte read
-    float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-    for (; j + 24 <= to; j += 16) {
-      const float4 b0 = q[4], b1 = q[5], b2 = q[6], b3 = q[7];
-      v += a0.x; v += a0.z; v += a1.x; v += a1.z; v += a2.x; v += a2.z; v += a3.x; v += a3.z;
-      a0 = q[8];
-      a1 = q[9];
-      a2 = q[10];
-      a3 = q[11];
-      v += b0.x; v += b0.z; v += b1.x; v += b1.z; v += b2.x; v += b2.z; v += b3.x; v += b3.z;
-      q += 8;
-    }
-    v += a0.x; v += a0.z; v += a1.x; v += a1.z; v += a2.x; v += a2.z; v += a3.x; v += a3.z;
-    j += 8;
+  if (n >= 16) {
+    PSA_LOAD(z, j + 16)
+    __builtin_amdgcn_sched_barrier(0);
+    PSA_ADDS(y)
+    PSA_ADDS_PART(z, j + 16)
+  } else {
+    PSA_ADDS_PART(y, j)
   }
-  for (; j < to; ++j) v += d12[j].x;
+#undef PSA_LOAD
+#undef PSA_ADDS
+#undef PSA_ADDS_PART
   return v;
 }
 
@@ -285,84 +381,95 @@ __device__ __forceinline__ float add_run_d1(const float2 *d12, int from, int to,
 // Lanes are skewed in time (lane p reads position p + t at step t), so every lane is in
 // the same phase and no per-lane selects are needed.  The smallest p that attains the
 // maximum wins.
+// Two positions are taken per iteration: with (c, v) in one register pair,
+//   {t0, v1} = {c, v} + {d2[j], d1[j]},   {t1, v2} = {t0, v1} + {d2[j+1], d1[j+1]}
+// are two packed adds, and  c'' = max(v1, c' + d2[j+1]) = max(v1, fl(v + d2[j+1]), t1)  because
+// fl(max(x, y) + d) = max(fl(x + d), fl(y + d)): the dependent chain through c is add, add, max3
+// per two positions instead of add, max per position, and the values are the same bit for bit.
 __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
+  PSA_TS_DECL()
+  PSA_TS()
   __shared__ int skip_flag[1];
   float *T = (float *)smem;
   const int tid = threadIdx.x;
   for (int i = tid; i < kDevTable; i += 256) T[i] = P.table_t[i];
   const unsigned nact = *P.nactive;
   const long long nitems = (long long)nact * P.pchunks;
+  PSA_TS()
   for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
     ActiveOffset ao;
     ao.seq = uni(P.active[item / P.pchunks].seq);
     ao.s = uni(P.active[item / P.pchunks].s);
     const int pc = (int)(item % P.pchunks);
+    // (requested together with the descriptor: one memory round trip, not three)
+    const int known_p = tid == 0 ? P.acc[ao.seq].res_p : 0;
+    const float fstar = key2f(P.acc[ao.seq].res_key);
     const SeqDesc d = load_desc(P.desc + ao.seq);
     const int L2 = d.len2;
     const int p0 = pc * 256;
     if (p0 > L2 - 2) continue;
     __syncthreads();
-    if (tid == 0) skip_flag[0] = p0 > P.acc[ao.seq].res_p;  // a smaller p is already known
+    if (tid == 0) skip_flag[0] = p0 > known_p;  // a smaller p is already known
     __syncthreads();
     if (uni(skip_flag[0])) continue;  // one decision for the whole block
     float *d0 = T + kDevTable;
-    float2 *d12 = (float2 *)(d0 + tie_d0_len(L2));
-    fill_diagonals(d0, d12, T, P, d, ao.s);
-    __syncthreads();
-    const float fstar = key2f(P.acc[ao.seq].res_key);
+    f2 *d21 = (f2 *)(d0 + tie_d0_len(L2));
+    PSA_TS()
+    fill_diagonals(d0, d21, T, P, d, ao.s);
+    PSA_TS()
     const int p = p0 + tid;
     // a_p: prefix of the undeleted chain; lane p keeps the value before position p
-    float v = add_run_d0(d0, 0, p0, 0.0f);
-    float mine = v;
+    float v = add_run<1, false>(d0, 0, p0, 0.0f, 0);
+    PSA_TS()
     const int pend = min(p0 + 256, L2 - 1);  // p <= L2 - 2
-    for (int j = p0; j < pend; ++j) {
-      mine = (j == p) ? v : mine;
-      v += d0[j];
-    }
-    // skewed chain: step t handles position p + 1 + t
-    const float2 *dp = d12 + p + 1;
-    const int nsteps = L2 - 1 - p0;
-    float c = -INFINITY;
-    v = mine;
+    const float mine = add_run<1, true>(d0, p0, pend, v, p);
+    PSA_TS()
+    // skewed chain: step t handles position p + 1 + t; whole groups of 16 (the padding is neutral:
+    // v is -inf from position L2 - 1 on, and c + 0 = c)
+    const f2 *dp = d21 + p + 1;
+    const int nsteps = (L2 - 1 - p0 + 15) & ~15;
+    f2 cv = {-INFINITY, mine};
+    f2 y[16], z[16];
+#define PSA_LOAD(r, t0) _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = dp[(t0) + k];
+#define PSA_STEPS(r)                                                              \
+  _Pragma("unroll") for (int k = 0; k < 16; k += 2) {                             \
+    const f2 a0 = cv + r[k];                                                      \
+    f2 a1 = a0 + r[k + 1];                                                        \
+    const float u = cv.y + r[k + 1].x;                                            \
+    a1.x = __builtin_fmaxf(__builtin_fmaxf(a0.y, u), a1.x);                       \
+    cv = a1;                                                                      \
+  }
+    PSA_LOAD(y, 0)
     int t = 0;
-    if (nsteps >= 8) {
-      float2 y[8], z[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) y[k] = dp[k];
-      for (; t + 24 <= nsteps; t += 16) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = dp[t + 8 + k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          c = fmaxf(v, c + y[k].y);
-          v = v + y[k].x;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) y[k] = dp[t + 16 + k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          c = fmaxf(v, c + z[k].y);
-          v = v + z[k].x;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        c = fmaxf(v, c + y[k].y);
-        v = v + y[k].x;
-      }
-      t += 8;
+    for (; t + 32 <= nsteps; t += 32) {
+      PSA_LOAD(z, t + 16)
+      __builtin_amdgcn_sched_barrier(0);
+      PSA_STEPS(y)
+      __builtin_amdgcn_sched_barrier(0);
+      PSA_LOAD(y, t + 32)
+      __builtin_amdgcn_sched_barrier(0);
+      PSA_STEPS(z)
     }
-    for (; t < nsteps; ++t) {
-      const float2 x = dp[t];
-      c = fmaxf(v, c + x.y);
-      v = v + x.x;
+    if (t < nsteps) {
+      PSA_STEPS(y)
     }
+#undef PSA_LOAD
+#undef PSA_STEPS
+    PSA_TS()
+    const float c = cv.x;
     int cand = (p <= L2 - 2 && c == fstar) ? p : INT_MAX;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) cand = min(cand, __shfl_xor(cand, m));
     if ((tid & 63) == 0 && cand != INT_MAX) atomicMin(&P.acc[ao.seq].res_p, cand);
+#ifdef PSA_TRACE
+    PSA_TS()
+    if (tid == 0 && blockIdx.x < 8)
+      printf("first_p blk %d p0 %d L2 %d: nact %llu desc %llu fill %llu prefix %llu hand %llu main %llu tail %llu\n", (int)blockIdx.x, p0,
+             L2, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4], ts_[6] - ts_[5], ts_[7] - ts_[6]);
+    nts_ = 2;
+#endif
   }
 }
 
@@ -372,74 +479,94 @@ __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
 __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
+  PSA_TS_DECL()
+  PSA_TS()
   __shared__ int skip_flag[1];
   float *T = (float *)smem;
   const int tid = threadIdx.x;
   for (int i = tid; i < kDevTable; i += 256) T[i] = P.table_t[i];
   const unsigned nact = *P.nactive;
   const long long nitems = (long long)nact * P.pchunks;
+  PSA_TS()
   for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
     ActiveOffset ao;
     ao.seq = uni(P.active[item / P.pchunks].seq);
     ao.s = uni(P.active[item / P.pchunks].s);
     const int qc = (int)(item % P.pchunks);
+    // (requested together with the descriptor: one memory round trip, not three)
+    const unsigned long long known = tid == 0 ? P.acc[ao.seq].res_loc : ~0ull;
+    const float fstar = key2f(P.acc[ao.seq].res_key);
+    const int pstar = uni(P.acc[ao.seq].res_p);
     const SeqDesc d = load_desc(P.desc + ao.seq);
     const int L2 = d.len2;
-    const int pstar = uni(P.acc[ao.seq].res_p);
     const int q0 = qc * 256;
     if (pstar == INT_MAX || q0 > L2 - 1 || q0 + 255 <= pstar) continue;
     __syncthreads();
-    if (tid == 0) {
-      const unsigned long long known = P.acc[ao.seq].res_loc;
-      skip_flag[0] = known != ~0ull && (int)(known >> 32) < q0;  // a smaller q is already known
-    }
+    if (tid == 0) skip_flag[0] = known != ~0ull && (int)(known >> 32) < q0;  // a smaller q is already known
     __syncthreads();
     if (uni(skip_flag[0])) continue;  // one decision for the whole block
     float *d0 = T + kDevTable;
-    float2 *d12 = (float2 *)(d0 + tie_d0_len(L2));
-    fill_diagonals(d0, d12, T, P, d, ao.s);
-    __syncthreads();
-    const float fstar = key2f(P.acc[ao.seq].res_key);
+    f2 *d21 = (f2 *)(d0 + tie_d0_len(L2));
+    PSA_TS()
+    fill_diagonals(d0, d21, T, P, d, ao.s);
+    PSA_TS()
     const int q = q0 + tid;
-    float v = add_run_d0(d0, 0, pstar, 0.0f);  // a_{p*}
+    const float *d1 = (const float *)d21 + 1;  // stride 2
+    float v = add_run<1, false>(d0, 0, pstar, 0.0f, 0);  // a_{p*}
     int j = pstar + 1;
     if (j < q0) {  // positions every lane of the block consumes
-      v = add_run_d1(d12, j, q0, v);
+      v = add_run<2, false>(d1, j, q0, v, 0);
       j = q0;
     }
-    float mine = v;
-    const int qend = min(q0 + 256, L2);
-    for (; j < qend; ++j) {
-      mine = (j == q) ? v : mine;               // value handed over when q is deleted
-      v += d12[j].x;
-    }
-    const float2 *dp = d12 + q + 1;
-    const int nsteps = L2 - 1 - q0;
+    PSA_TS()
+    // the value handed over when q is deleted: the chain before position q
+    const float mine = add_run<2, true>(d1, j, min(q0 + 256, L2), v, q);
+    PSA_TS()
+    // skewed chain over d2, whole groups of 16 (the padding adds +0.0)
+    const float *dp = (const float *)(d21 + q + 1);
+    const int nsteps = (L2 - 1 - q0 + 15) & ~15;
     float c = mine;
+    float y[16], z[16];
+#define PSA_LOAD(r, t0) _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = dp[2 * ((t0) + k)];
+#define PSA_ADDS(r) _Pragma("unroll") for (int k = 0; k < 16; ++k) c += r[k];
+    PSA_LOAD(y, 0)
     int t = 0;
-    if (nsteps >= 8) {
-      float y[8], z[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) y[k] = dp[k].y;
-      for (; t + 24 <= nsteps; t += 16) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = dp[t + 8 + k].y;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c += y[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) y[k] = dp[t + 16 + k].y;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c += z[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) c += y[k];
-      t += 8;
+#define PSA_TWO_GROUPS()                   \
+  PSA_LOAD(z, t + 16)                      \
+  __builtin_amdgcn_sched_barrier(0);       \
+  PSA_ADDS(y)                              \
+  __builtin_amdgcn_sched_barrier(0);       \
+  PSA_LOAD(y, t + 32)                      \
+  __builtin_amdgcn_sched_barrier(0);       \
+  PSA_ADDS(z)                              \
+  __builtin_amdgcn_sched_barrier(0);       \
+  t += 32;
+    // (64 positions per iteration: the 16 values carried into the next iteration are copied once)
+    while (t + 64 <= nsteps) {
+      PSA_TWO_GROUPS()
+      PSA_TWO_GROUPS()
     }
-    for (; t < nsteps; ++t) c += dp[t].y;
+    if (t + 32 <= nsteps) {
+      PSA_TWO_GROUPS()
+    }
+#undef PSA_TWO_GROUPS
+    if (t < nsteps) {
+      PSA_ADDS(y)
+    }
+#undef PSA_LOAD
+#undef PSA_ADDS
+    PSA_TS()
     unsigned long long cand = ~0ull;
     if (q > pstar && q <= L2 - 1 && c == fstar) cand = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)ao.s;
     cand = wave_min_u64(cand);
     if ((tid & 63) == 0 && cand != ~0ull) atomicMin(&P.acc[ao.seq].res_loc, cand);
+#ifdef PSA_TRACE
+    PSA_TS()
+    if (tid == 0 && blockIdx.x < 8)
+      printf("first_q blk %d q0 %d pstar %d L2 %d: nact %llu desc %llu fill %llu prefix %llu hand %llu main %llu tail %llu\n", (int)blockIdx.x, q0,
+             pstar, L2, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4], ts_[6] - ts_[5], ts_[7] - ts_[6]);
+    nts_ = 2;
+#endif
   }
 }
 
@@ -569,6 +696,37 @@ hipError_t debug_sync(const char *what) {
   return e;
 }
 
+// Set-up of a small batch in one launch: the work lists staged in pinned host memory (read
+// through its device mapping, 16 bytes per thread) go to their device block, the accumulators
+// and counters get their initial values and the per-chunk keys are cleared -- instead of an
+// asynchronous copy, a memset and psa_init_acc on two streams with an event between them.
+__global__ __launch_bounds__(256) void psa_setup_small(const uint4 *src, uint4 *dst, int n16, SeqAcc *acc, int nacc,
+                                                        unsigned *counters, int ncounters, unsigned long long *best,
+                                                        int nbest) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+  if (i < nacc) {
+    SeqAcc a;
+    a.enum_key = 0ull;
+    a.enum_loc = ~0ull;
+    a.res_loc = ~0ull;
+    a.res_key = 0u;
+    a.res_p = INT_MAX;
+    acc[i] = a;
+  }
+  if (i < ncounters) counters[i] = 0u;
+  for (int k = i; k < nbest; k += gridDim.x * blockDim.x) best[k] = 0ull;
+}
+
+hipError_t launch_setup_small(const void *src, void *dst, size_t bytes, SeqAcc *acc, int nacc, unsigned *counters,
+                              int ncounters, unsigned long long *best, size_t nbest, hipStream_t st) {
+  const int n16 = (int)((bytes + 15) / 16);
+  const int m = std::max(std::max(n16, nacc), std::max(ncounters, (int)std::min<size_t>(nbest, 1 << 16)));
+  hipLaunchKernelGGL(psa_setup_small, dim3((m + 255) / 256), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n16, acc,
+                     nacc, counters, ncounters, best, (int)nbest);
+  return hipGetLastError();
+}
+
 hipError_t launch_init(SeqAcc *acc, int n, unsigned *counters, int ncounters, hipStream_t st) {
   int m = n > ncounters ? n : ncounters;
   hipLaunchKernelGGL(psa_init_acc, dim3((m + 255) / 256), dim3(256), 0, st, acc, n, counters, ncounters);
@@ -579,7 +737,8 @@ static size_t fwd_lds(int max_len2) {
   return (size_t)kDevTable * 4 + 4 * (size_t)fwd_rows(max_len2) + 4 * (size_t)fwd_window(max_len2) + 64;
 }
 static size_t tie_lds(int max_len2) {
-  return (size_t)kDevTable * 4 + 4 * (size_t)tie_d0_len(max_len2) + 8 * (size_t)tie_d12_len(max_len2);
+  return (size_t)kDevTable * 4 + 4 * (size_t)tie_d0_len(max_len2) + 8 * (size_t)tie_d21_len(max_len2) +
+         2 * (size_t)tie_codes_len(max_len2);
 }
 
 // The dynamic-LDS limits of the resolve kernels for the device that is current: once per context

@@ -15,7 +15,8 @@ import weakref
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "libpsa_hip.so")
+# PSA_HIP_LIB names another build of the library to load (comparing two builds in one session)
+LIB_PATH = os.environ.get("PSA_HIP_LIB") or os.path.join(os.path.dirname(_PKG), "libpsa_hip.so")
 
 PSA_TABLE_SIZE = 676
 STAGE_ENUMERATE = 1
