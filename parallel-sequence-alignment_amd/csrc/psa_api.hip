@@ -817,11 +817,12 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       const bool mfma_loop = b->mfma_loop;
       int lds = b->cap_loops && !mfma_loop ? 41 * 1024 : 0;
       if (const char *e = std::getenv("PSA_ENUM_LDS_KB")) lds = std::max(0, std::min(64, std::atoi(e))) * 1024;  // tuning aid
-      // capped launches keep workgroups of 8 waves (the cap counts workgroups); the others use
-      // workgroups of one wave, which take a wave slot as soon as one is free
-      // (the matrix-core loop is capped by its registers at 4 waves per SIMD; small batches run it in
-      // workgroups of 4 waves: 0.180 against 0.190 ms per step of 4 x Seq2 = 2000 with 8-wave workgroups)
-      int wpg = b->cap_loops ? (mfma_loop ? 4 : 8) : 1;
+      // small batches (capped launches) use workgroups of 8 waves, the others workgroups of one wave,
+      // which take a wave slot as soon as one is free.  (Small batches with the matrix-core loop: whole
+      // steps of 4 x Seq2 = 2000 enqueued back to back take 0.180 ms with 8-wave workgroups, 0.192 ms
+      // with 4 and 0.25 ms with 1 or 2: the short kernels of the other streams are placed sooner
+      // when a retiring workgroup frees two wave slots per SIMD at once.)
+      int wpg = b->cap_loops ? 8 : 1;
       if (const char *e = std::getenv("PSA_ENUM_WPG")) wpg = std::max(1, std::min(8, std::atoi(e)));  // tuning aid
       PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;

@@ -519,13 +519,21 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
 #pragma unroll
   for (int pb = 0; pb < 8; ++pb) m[pb] = __int_as_float(Cand<true>::lowest);
   int soff = 0;  // byte offset of the current row
-  int fn[4];
+  // Loads are issued unconditionally, at clamped addresses, and in one place per offset: the
+  // compiler then counts them exactly, and no wait covers a load younger than one offset's work.
+  // (With loads under conditions it waited for everything outstanding, including the requests
+  // it had just issued for the next offset: a full memory latency per offset and level.)
+  //   fn[r]  next offset's f (its row is the one after this offset's), run pc0 + r of p
+  //   gn[k]  next offset's g for the level's own 256 positions, run pc0 + k
+  const int step = 4 * rowlen;  // bytes from one offset's row to the next
+  auto vq = [&](int q) { return 4 * (min(q, qend) + lane); };  // past the row: its run of padding
+  int fn[4], gn[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), soff + 4 * rowlen, 0);
+  for (int r = 0; r < 4; ++r) {
+    fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), soff + step, 0);
+    gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q00 + 64 * r), soff, 0);
+  }
   int tn = G[rowlen + qend];  // the constant of the next row
-  // the first two steps of an offset's row of g are requested while the offset before is scored
-  int gfirst0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), soff, 0);
-  int gfirst1 = q00 + 64 < qend ? __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + 64 + lane), soff, 0) : 0;
   for (int i = r0; i < r1; ++i) {
     i32x4 B[8];
     {
@@ -534,49 +542,57 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
       for (int r = 0; r < 4; ++r) f[r] = Cand<true>::sub(fn[r], tn);
       mfma_build_b(f, B);
     }
-    const int grow = soff;  // this offset's row of g
-    soff += 4 * rowlen;
-    if (i + 1 < r1) {  // next offset's f values arrive while this one is scored
+    // operands of the level's own four steps
+    i32x4 A0[4], A1[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), soff + 4 * rowlen, 0);
-      tn = G[2 * rowlen + qend];
-    }
+    for (int k = 0; k < 4; ++k) mfma_build_a(gn[k], A0[k], A1[k]);
+    const int grow = soff;  // this offset's row of g
+    const int adv = i + 1 < r1 ? step : 0;  // the last offset of the unit requests its own rows again
+    soff += step;
     G += rowlen;
-    int g0 = gfirst0, g1 = gfirst1;
-    if (i + 1 < r1) {
-      gfirst0 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + lane), soff, 0);
-      if (q00 + 64 < qend) gfirst1 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q00 + 64 + lane), soff, 0);
+    {
+      const int nrow = grow + adv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), nrow + step, 0);
+        gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q00 + 64 * r), nrow, 0);
+      }
+      tn = (G - rowlen)[(adv ? 2 : 1) * rowlen + qend];
     }
-    int q = q00;
+    int q = q00 + 256;
+    // the first three steps beyond the level's own positions, requested before those are scored
+    int g[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q + 64 * k), grow, 0);  // (used ~36 tiles later)
     // the level's own 256 positions: blocks 0..7 of q against the blocks of p below and at them
-#define PSA_OWN_STEP(RB)                                                                            \
-    if (q < qend) {                                                                                   \
-      int g2 = 0;                                                                                     \
-      if (q + 128 < qend) g2 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q + 128 + lane), grow, 0); \
-      i32x4 a0, a1;                                                                                   \
-      mfma_build_a(g0, a0, a1);                                                                       \
-      mfma_own_block<RB>(a0, B, mask, m);                                                             \
-      if (q + 32 < L2) mfma_own_block<RB + 1>(a1, B, mask, m);                                        \
-      g0 = g1;                                                                                        \
-      g1 = g2;                                                                                        \
-      q += 64;                                                                                        \
+#define PSA_OWN_STEP(K)                                                          \
+    if (q00 + 64 * K < qend) {                                                     \
+      mfma_own_block<2 * K>(A0[K], B, mask, m);                                    \
+      if (q00 + 64 * K + 32 < L2) mfma_own_block<2 * K + 1>(A1[K], B, mask, m);    \
     }
     PSA_OWN_STEP(0)
+    PSA_OWN_STEP(1)
     PSA_OWN_STEP(2)
-    PSA_OWN_STEP(4)
-    PSA_OWN_STEP(6)
+    PSA_OWN_STEP(3)
 #undef PSA_OWN_STEP
-    // beyond them every (p, q) pair is a candidate
+    // beyond them every (p, q) pair is a candidate; the row is requested three steps ahead into
+    // four registers that take turns (no copies, and a wait only ever covers a load three steps old)
     const f32x16 z = {};
-    for (; q < qend; q += 64) {
-      int g2 = 0;
-      if (q + 128 < qend) g2 = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (q + 128 + lane), grow, 0);
-      i32x4 a0, a1;
-      mfma_build_a(g0, a0, a1);
-      mfma_tiles<8>(a0, B, z, m);
-      if (q + 32 < L2) mfma_tiles<8>(a1, B, z, m);
-      g0 = g1;
-      g1 = g2;
+    for (; q < qend; q += 256) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // (past the row's end the request repeats this step's own run, which the wave read three
+        // steps ago and the CU's cache still holds: the loads stay unconditional, so the compiler
+        // counts them exactly, and none is still in flight when the next offset waits for its rows)
+        const int qn = q + 64 * k + 192 < qend ? q + 64 * k + 192 : q + 64 * k;
+        g[(k + 3) & 3] = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (qn + lane), grow, 0);
+        if (q + 64 * k < qend) {
+          i32x4 a0, a1;
+          mfma_build_a(g[k], a0, a1);
+          mfma_tiles<8>(a0, B, z, m);
+          if (q + 64 * k + 32 < L2) mfma_tiles<8>(a1, B, z, m);
+        }
+      }
     }
   }
   // best fixed-point score of this unit and the smallest p attaining it; lanes l and l + 32 hold

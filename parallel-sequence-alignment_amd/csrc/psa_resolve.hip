@@ -322,9 +322,16 @@ __device__ __forceinline__ void fill_diagonals(float *d0, f2 *d21, const float *
   __syncthreads();
 }
 
+// Values requested per group in the chains below (two groups of registers take turns).
+#ifndef PSA_TIE_GROUP
+#define PSA_TIE_GROUP 16
+#endif
+constexpr int kG = PSA_TIE_GROUP;
+static_assert(kG == 8 || kG == 16, "group of 8 or 16");
+
 // Serial float32 chains over LDS arrays.  The adds are dependent by nature (the reference's
 // rounding order) and a lone wave issues a dependent add every 10.5 cycles; what can be hidden
-// is the LDS latency: the next 16 values are requested before the current 16 are added (the
+// is the LDS latency: the next kG values are requested before the current kG are added (the
 // scheduling barriers keep the compiler from sinking the requests below the adds, or from
 // hoisting them into the adds, which costs a second set of registers and copies).
 //
@@ -332,40 +339,40 @@ __device__ __forceinline__ void fill_diagonals(float *d0, f2 *d21, const float *
 // lane `my` stops before position `my`: it adds +0.0 from there on (which changes no value), so
 // that it ends with the value of the chain before position `my` -- the compare and the select
 // that zero an element do not depend on the chain, only the add does.
-// Reads up to 32 elements past `to` (the arrays are padded).
+// Reads up to 2 kG elements past `to` (the arrays are padded).
 template <int STRIDE, bool HAND>
 __device__ __forceinline__ float add_run(const float *src, int from, int to, float v, int my) {
   int n = to - from;
   if (n <= 0) return v;
   int j = from;
   int rel = my - from;  // positions this lane still adds
-  float y[16], z[16];
+  float y[kG], z[kG];
 #define PSA_LOAD(r, j0)                                                  \
-  _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = src[STRIDE * ((j0) + k)];
+  _Pragma("unroll") for (int k = 0; k < kG; ++k) r[k] = src[STRIDE * ((j0) + k)];
 #define PSA_ADDS(r)                                                       \
-  _Pragma("unroll") for (int k = 0; k < 16; ++k) v += HAND ? (k < rel ? r[k] : 0.0f) : r[k]; \
-  rel -= 16;
+  _Pragma("unroll") for (int k = 0; k < kG; ++k) v += HAND ? (k < rel ? r[k] : 0.0f) : r[k]; \
+  rel -= kG;
 #define PSA_ADDS_PART(r, j0)                                              \
-  _Pragma("unroll") for (int k = 0; k < 16; ++k)                          \
+  _Pragma("unroll") for (int k = 0; k < kG; ++k)                          \
     if ((j0) + k < to) v += HAND ? (k < rel ? r[k] : 0.0f) : r[k];       \
-  rel -= 16;
+  rel -= kG;
   PSA_LOAD(y, j)
-  while (n >= 32) {
-    PSA_LOAD(z, j + 16)
+  while (n >= 2 * kG) {
+    PSA_LOAD(z, j + kG)
     __builtin_amdgcn_sched_barrier(0);
     PSA_ADDS(y)
     __builtin_amdgcn_sched_barrier(0);
-    PSA_LOAD(y, j + 32)
+    PSA_LOAD(y, j + 2 * kG)
     __builtin_amdgcn_sched_barrier(0);
     PSA_ADDS(z)
-    j += 32;
-    n -= 32;
+    j += 2 * kG;
+    n -= 2 * kG;
   }
-  if (n >= 16) {
-    PSA_LOAD(z, j + 16)
+  if (n >= kG) {
+    PSA_LOAD(z, j + kG)
     __builtin_amdgcn_sched_barrier(0);
     PSA_ADDS(y)
-    PSA_ADDS_PART(z, j + 16)
+    PSA_ADDS_PART(z, j + kG)
   } else {
     PSA_ADDS_PART(y, j)
   }
@@ -426,15 +433,15 @@ __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
     const int pend = min(p0 + 256, L2 - 1);  // p <= L2 - 2
     const float mine = add_run<1, true>(d0, p0, pend, v, p);
     PSA_TS()
-    // skewed chain: step t handles position p + 1 + t; whole groups of 16 (the padding is neutral:
+    // skewed chain: step t handles position p + 1 + t; whole groups of kG (the padding is neutral:
     // v is -inf from position L2 - 1 on, and c + 0 = c)
     const f2 *dp = d21 + p + 1;
-    const int nsteps = (L2 - 1 - p0 + 15) & ~15;
+    const int nsteps = (L2 - 1 - p0 + kG - 1) & ~(kG - 1);
     f2 cv = {-INFINITY, mine};
-    f2 y[16], z[16];
-#define PSA_LOAD(r, t0) _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = dp[(t0) + k];
+    f2 y[kG], z[kG];
+#define PSA_LOAD(r, t0) _Pragma("unroll") for (int k = 0; k < kG; ++k) r[k] = dp[(t0) + k];
 #define PSA_STEPS(r)                                                              \
-  _Pragma("unroll") for (int k = 0; k < 16; k += 2) {                             \
+  _Pragma("unroll") for (int k = 0; k < kG; k += 2) {                             \
     const f2 a0 = cv + r[k];                                                      \
     f2 a1 = a0 + r[k + 1];                                                        \
     const float u = cv.y + r[k + 1].x;                                            \
@@ -443,12 +450,12 @@ __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
   }
     PSA_LOAD(y, 0)
     int t = 0;
-    for (; t + 32 <= nsteps; t += 32) {
-      PSA_LOAD(z, t + 16)
+    for (; t + 2 * kG <= nsteps; t += 2 * kG) {
+      PSA_LOAD(z, t + kG)
       __builtin_amdgcn_sched_barrier(0);
       PSA_STEPS(y)
       __builtin_amdgcn_sched_barrier(0);
-      PSA_LOAD(y, t + 32)
+      PSA_LOAD(y, t + 2 * kG)
       __builtin_amdgcn_sched_barrier(0);
       PSA_STEPS(z)
     }
@@ -522,31 +529,31 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
     // the value handed over when q is deleted: the chain before position q
     const float mine = add_run<2, true>(d1, j, min(q0 + 256, L2), v, q);
     PSA_TS()
-    // skewed chain over d2, whole groups of 16 (the padding adds +0.0)
+    // skewed chain over d2, whole groups of kG (the padding adds +0.0)
     const float *dp = (const float *)(d21 + q + 1);
-    const int nsteps = (L2 - 1 - q0 + 15) & ~15;
+    const int nsteps = (L2 - 1 - q0 + kG - 1) & ~(kG - 1);
     float c = mine;
-    float y[16], z[16];
-#define PSA_LOAD(r, t0) _Pragma("unroll") for (int k = 0; k < 16; ++k) r[k] = dp[2 * ((t0) + k)];
-#define PSA_ADDS(r) _Pragma("unroll") for (int k = 0; k < 16; ++k) c += r[k];
+    float y[kG], z[kG];
+#define PSA_LOAD(r, t0) _Pragma("unroll") for (int k = 0; k < kG; ++k) r[k] = dp[2 * ((t0) + k)];
+#define PSA_ADDS(r) _Pragma("unroll") for (int k = 0; k < kG; ++k) c += r[k];
     PSA_LOAD(y, 0)
     int t = 0;
 #define PSA_TWO_GROUPS()                   \
-  PSA_LOAD(z, t + 16)                      \
+  PSA_LOAD(z, t + kG)                      \
   __builtin_amdgcn_sched_barrier(0);       \
   PSA_ADDS(y)                              \
   __builtin_amdgcn_sched_barrier(0);       \
-  PSA_LOAD(y, t + 32)                      \
+  PSA_LOAD(y, t + 2 * kG)                      \
   __builtin_amdgcn_sched_barrier(0);       \
   PSA_ADDS(z)                              \
   __builtin_amdgcn_sched_barrier(0);       \
-  t += 32;
-    // (64 positions per iteration: the 16 values carried into the next iteration are copied once)
-    while (t + 64 <= nsteps) {
+  t += 2 * kG;
+    // (4 kG positions per iteration: the kG values carried into the next iteration are copied once)
+    while (t + 4 * kG <= nsteps) {
       PSA_TWO_GROUPS()
       PSA_TWO_GROUPS()
     }
-    if (t + 32 <= nsteps) {
+    if (t + 2 * kG <= nsteps) {
       PSA_TWO_GROUPS()
     }
 #undef PSA_TWO_GROUPS
