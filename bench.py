@@ -53,15 +53,18 @@ WEIGHTS = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)  # the reference's inpu
 # clock 2400 MHz)
 PEAK_INT32_LANE_OPS = 256 * 4 * 32 * 2.4e9
 OPS_PER_CANDIDATE = 2  # one add (f[p] + g[q]) and one max per (offset, mutant) candidate
-# The candidate loop forms the sums of 32 x 32 candidates with one v_mfma_f32_32x32x16_bf16 and takes
-# their maxima with 8 v_max3_f32.  What bounds it is the SIMD's vector issue port: a v_max3_f32 takes
-# 4 cycles of it and the matrix instruction holds it for 8 of its 32 (MI355X_MICROARCH.md, cycle
-# constants: vector-instruction issue cost), so a tile cannot take less than 40 cycles of one SIMD;
-# measured with nothing else in the loop: 41.4 (tools/valu_bench10.hip, profiles/r02_valu_mfma_ceilings.txt).
+# The candidate loop forms the sums of 32 x 32 candidates with one v_mfma_f32_32x32x8_bf16_1k and takes
+# their maxima with 8 v_max3_f32.  Either half bounds a tile at 32 cycles of one SIMD: the matrix core
+# is occupied for 32 cycles by the instruction (tools/valu_bench10.hip mode 7: 32.0 measured back to
+# back), and the vector issue port for 8 x 4 cycles by the maxima (MI355X_MICROARCH.md, cycle
+# constants: vector-instruction issue cost).  Measured with nothing else in the loop: 37.4 cycles per
+# tile at 8 waves per SIMD, 39.5 at 4 (mode 8; profiles/r02_valu_mfma_ceilings.txt) -- the matrix
+# instruction also takes issue slots of the port.
 SIMDS = 256 * 4
 PEAK_CLOCK_HZ = 2.4e9
-ISSUE_CYCLES_PER_TILE = 40.0
-PEAK_CANDIDATES = SIMDS * PEAK_CLOCK_HZ * 1024.0 / ISSUE_CYCLES_PER_TILE  # 6.29e13 candidates/s
+CYCLES_PER_TILE_BOUND = 32.0
+BARE_LOOP_CYCLES_PER_TILE = {"4 waves per SIMD": 39.5, "8 waves per SIMD": 37.4}
+PEAK_CANDIDATES = SIMDS * PEAK_CLOCK_HZ * 1024.0 / CYCLES_PER_TILE_BOUND  # 7.86e13 candidates/s
 
 
 def tiles_per_offset(L2):
@@ -493,31 +496,35 @@ def roofline_block(cfg, w):
     clk = w["clock_mhz"] * 1e6
     cyc_per_tile = kern_s * clk * SIMDS / tiles if clk > 0 else None
     return dict(common, **{
-        "bound": "valu-issue", "kernel": "psa_enum_wave_mfma",
+        "bound": "mfma", "kernel": "psa_enum_wave_mfma",
         "achieved": achieved / 1e12, "peak": PEAK_CANDIDATES / 1e12, "unit": "Tcandidates/s",
         "frac": achieved / PEAK_CANDIDATES,
+        # the same in the matrix instruction's own flops (32 x 32 x 8 x 2 per 1024 candidates): half the bf16
+        # dense peak of the chip, because the K = 8 form does half the K = 16 form's products in the same 32 cycles
+        "achieved_tflops": achieved * 16.0 / 1e12, "peak_tflops": PEAK_CANDIDATES * 16.0 / 1e12,
         # the same with the whole step in the denominator (pre-pass, locate, records and every gap included)
         "step_frac": cand_rank * steps / my_elapsed / PEAK_CANDIDATES,
         # clock the chip held under this kernel (its waves' shader cycles / 100 MHz ticks, measured by this run)
         "clock_mhz_measured": w["clock_mhz"],
         "tiles_per_launch": tiles,
         "candidates_per_tile": cand_rank / tiles,
-        "issue_ceiling_cycles_per_tile": ISSUE_CYCLES_PER_TILE,
+        "bound_cycles_per_tile": CYCLES_PER_TILE_BOUND,
+        "bare_loop_cycles_per_tile": BARE_LOOP_CYCLES_PER_TILE,
         "cycles_per_tile_measured": cyc_per_tile,
-        # how close the kernel's tiles come to the issue ceiling, at the clock it really ran at: <= 1 by construction
-        "issue_frac_at_measured_clock": ISSUE_CYCLES_PER_TILE / cyc_per_tile if cyc_per_tile else None,
+        # tiles against the 32-cycle bound at the clock the kernel really ran at (<= 1 by construction):
+        # the share of the time the matrix cores are busy, and equally the share the maxima alone need of the port
+        "matrix_core_busy_frac": CYCLES_PER_TILE_BOUND / cyc_per_tile if cyc_per_tile else None,
         "frac_at_measured_clock": achieved / (PEAK_CANDIDATES * clk / PEAK_CLOCK_HZ) if clk > 0 else None,
-        "matrix_core_busy_frac": tiles * 32.0 / (kern_s * clk * SIMDS) if clk > 0 else None,
-        "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz x 1024 candidates per 40 cycles of vector issue (one "
-                "v_mfma_f32_32x32x16_bf16 holding the port for 8 cycles + 8 v_max3_f32 at 4: the kernel's own "
-                "instruction mix, nothing else); achieved = candidates per launch / HIP-event time of the "
-                "candidate-loop kernel(s) of a step, events attached to the kernel dispatches on their stream, "
-                "measured on steps launched one at a time after the timed region (inside it two launches share "
-                "the GPU: kernel_ms_pipelined).  frac counts candidates, so tiles along the diagonal (half "
-                "empty) and row padding weigh against it; issue_frac_at_measured_clock counts tiles at the "
-                "measured clock.  The kernel reads 4 bytes of slab per (offset, position) against L2/2 "
-                "candidates each (hbm_frac of the 8 TB/s peak): vector issue bounds it, not HBM, and the "
-                "matrix cores are busy matrix_core_busy_frac of the time"})
+        "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz x 1024 candidates per 32 cycles: one "
+                "v_mfma_f32_32x32x8_bf16_1k occupies the SIMD's matrix core for 32 cycles, and the 8 v_max3_f32 that "
+                "reduce its tile take 8 x 4 cycles of the vector issue port -- either bounds a tile at 32 (the bare "
+                "loop measures 37.4-39.5: bare_loop_cycles_per_tile).  achieved = candidates per launch / "
+                "HIP-event time of the candidate-loop kernel(s) of a step, events attached to the kernel dispatches "
+                "on their stream, measured on steps launched one at a time after the timed region (inside it two "
+                "launches share the GPU: kernel_ms_pipelined).  frac counts candidates, so tiles along the diagonal "
+                "(half empty) and row padding weigh against it; matrix_core_busy_frac counts tiles at the measured "
+                "clock.  The kernel reads 4 bytes of slab per (offset, position) against L2/2 candidates each "
+                "(hbm_frac of the 8 TB/s peak): HBM does not bound it"})
 
 
 def host_inclusive(ctx, seq1, seq2s, calls=20):

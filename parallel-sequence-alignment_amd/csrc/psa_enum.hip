@@ -369,35 +369,35 @@ __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int
   if (q < qb) wave_step16<R, R, F32>(ga, f, acc);
 }
 
-// ---- long phase on the matrix cores --------------------------------------------------
+// ---- candidate sums on the matrix cores --------------------------------------------------
 // f[p] + g[q] for 32 q x 32 p is the product of a 32 x K and a K x 32 matrix whose entries are
-// pieces of the values and ones: sum_k A[q][k] B[k][p] with A = (1, 1, 1, g_hi, g_mid, g_lo),
-// B = (f_hi, f_mid, f_lo, 1, 1, 1).  f and g are integers of at most 25 significant bits held in
+// pieces of the values and ones: sum_k A[q][k] B[k][p] with A = (g_hi, g_mid, g_lo, 0, 1, 1, 1, 0),
+// B = (1, 1, 1, 0, f_hi, f_mid, f_lo, 0).  f and g are integers of at most 25 significant bits held in
 // float32, so each splits exactly into three bfloat16 values (8 significant bits each): hi = the
 // value with its low 16 bits cleared, mid likewise of the remainder, lo the rest.  Every product
 // is exact, every partial sum of pieces is an integer no larger than the larger of |f|, |g| and
-// |f + g| <= 2^24, so the float32 accumulation inside v_mfma_f32_32x32x16_bf16 is exact in any
-// order and the tile holds the same 1024 integers the add instructions would give.  One such
-// instruction occupies the matrix core for 32 cycles and the vector issue port for 8; the 16
-// sums per lane then cost 8 v_max3_f32 (32 cycles), against 16 v_add_f32 + 8 v_max3_f32 for the
-// same 1024 candidates on the vector ALU alone (measured: 5.2 against 6.5 cycles per 128 candidates).
+// |f + g| <= 2^24, so the float32 accumulation inside the matrix instruction is exact in any
+// order and the tile holds the same 1024 integers the add instructions would give.
+// The instruction is v_mfma_f32_32x32x8_bf16_1k: K = 8 is all the product needs, its operands are
+// two registers each instead of four, it occupies the matrix core for 32 cycles like the K = 16
+// form but holds the vector issue port for fewer of them (measured with the 8 v_max3_f32 that
+// reduce a tile, four waves per SIMD: 39.5 against 43.4 cycles per tile; the vector ALU alone,
+// 16 v_add_f32 + 8 v_max3_f32 for the same 1024 candidates, takes 66).
 //
-// Operand layout of v_mfma_f32_32x32x16_bf16 (lane l, r = l & 31, h = l >> 5): A[row r][k = 8h + j]
-// and B[k = 8h + j][col r] for element j = 0..7 (two per operand register); result register v of
-// lane l is row (v & 3) + 8 (v >> 2) + 4h, column r.  Columns are positions p (a lane keeps the
-// running maximum of its own p over the rows, i.e. over q), rows are positions q.  The lower 32
-// lanes supply k = 0..7, the upper 32 lanes k = 8..15, so the pieces of one value are spread over
-// both halves: its (hi | mid) pair in the lower lane of its row or column, its (lo | 0) pair in
-// the upper lane, in the same operand register; the other operand holds ones there:
-//   A: register 0 = (g_hi | g_mid) in lane r, (g_lo | 0) in lane r + 32;  register 1 = (1 | 1);  2, 3 = 0
-//   B: register 0 = (1 | 1);  register 1 = (f_hi | f_mid) in lane c, (f_lo | 0) in lane c + 32;  2, 3 = 0
-// Two registers that hold the (hi | mid) and the (lo | 0) pairs of 64 consecutive values (lane =
-// position) turn into the operand registers of the two blocks of 32 with one v_permlane32_swap_b32,
-// which exchanges the upper half of its first register with the lower half of its second.
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
+// Operand layout (lane l, r = l & 31, h = l >> 5): A[row r][k = 4h + j] and B[k = 4h + j][col r] for
+// element j = 0..3 (two per operand register); result register v of lane l is row
+// (v & 3) + 8 (v >> 2) + 4h, column r.  Columns are positions p (a lane keeps the running maximum
+// of its own p over the rows, i.e. over q), rows are positions q.  So
+//   A: lanes  0..31 (k = 0..3) = (g_hi | g_mid), (g_lo | 0) of row r;   lanes 32..63 (k = 4..7) = (1 | 1), (1 | 0)
+//   B: lanes  0..31            = (1 | 1), (1 | 0);   lanes 32..63 = (f_hi | f_mid), (f_lo | 0) of column r
+// With the packed pieces of 64 consecutive values in two registers (lane = position),
+// v_permlane32_swap_b32 against a register of ones yields the operand registers of BOTH blocks of
+// 32 at once: it exchanges the upper half of its first register with the lower half of its second.
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-constexpr int kOnesBf16 = 0x3f803f80;  // (1.0, 1.0) as two bfloat16
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+constexpr int kOnesBf16 = 0x3f803f80;   // (1.0, 1.0) as two bfloat16
+constexpr int kOneLoBf16 = 0x00003f80;  // (1.0, 0.0)
 
 // x = hi + mid + lo exactly; p0 = (hi | mid << 16), p1 = (lo | 0) as packed bfloat16
 __device__ __forceinline__ void split_bf16x3(int xbits, int &p0, int &p1) {
@@ -410,23 +410,25 @@ __device__ __forceinline__ void split_bf16x3(int xbits, int &p0, int &p1) {
   p1 = (int)((unsigned)__float_as_int(lo) >> 16);
 }
 
-// B operands of the wave's 8 blocks of 32 positions p from its 4 registers of f (lane = position)
-__device__ __forceinline__ void mfma_build_b(const int (&f)[4], i32x4 (&B)[8]) {
+// B operands of the wave's 8 blocks of 32 positions p from its 4 registers of f (lane = position):
+// ones in the lower lanes, the pieces of the block's positions in the upper lanes
+__device__ __forceinline__ void mfma_build_b(const int (&f)[4], i32x2 (&B)[8]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     int p0, p1;
     split_bf16x3(f[r], p0, p1);
-    // [p0.low | p1.low] = positions 64 r + 0..31, [p0.high | p1.high] = positions 64 r + 32..63
-    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)p1, false, false);
-    B[2 * r] = i32x4{kOnesBf16, (int)sw[0], 0, 0};
-    B[2 * r + 1] = i32x4{kOnesBf16, (int)sw[1], 0, 0};
+    // [ones.low | p.low] = block of positions 64 r + 0..31, [ones.high | p.high] = positions 64 r + 32..63
+    const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)kOnesBf16, (unsigned)p0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)kOneLoBf16, (unsigned)p1, false, false);
+    B[2 * r] = i32x2{(int)s0[0], (int)s1[0]};
+    B[2 * r + 1] = i32x2{(int)s0[1], (int)s1[1]};
   }
 }
 
 // one tile: 32 q (operand a) x 32 p (operand b) on top of c (zero, or the diagonal tile's mask);
 // running maxima of the lane's column
-__device__ __forceinline__ f32x16 mfma_sums(const i32x4 &a, const i32x4 &b, const f32x16 &c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma_sums(const i32x2 &a, const i32x2 &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(bf16x4, a), __builtin_bit_cast(bf16x4, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_reduce(const f32x16 &d, float &m) {
   // a tree over the 16 results, the running maximum joining last: 8 v_max3_f32
@@ -444,7 +446,7 @@ __device__ __forceinline__ void mfma_reduce(const f32x16 &d, float &m) {
 // (two result tiles in registers; the order is pinned, the compiler otherwise puts each tile's
 // maxima right behind its own matrix instruction and the wave idles through its latency).
 template <int N>
-__device__ __forceinline__ void mfma_tiles(const i32x4 &a, const i32x4 (&B)[8], const f32x16 &c_last, float (&m)[8]) {
+__device__ __forceinline__ void mfma_tiles(const i32x2 &a, const i32x2 (&B)[8], const f32x16 &c_last, float (&m)[8]) {
   const f32x16 z = {};
   f32x16 d = mfma_sums(a, B[0], N == 1 ? c_last : z);
 #pragma unroll
@@ -460,21 +462,69 @@ __device__ __forceinline__ void mfma_tiles(const i32x4 &a, const i32x4 (&B)[8], 
   }
 }
 
-// A operands of the two blocks of 32 consecutive q whose g values the lanes hold (lane = position)
-__device__ __forceinline__ void mfma_build_a(int g, i32x4 &a0, i32x4 &a1) {
+// A operands of the two blocks of 32 consecutive q whose g values the lanes hold (lane = position):
+// the pieces of the block's positions in the lower lanes, ones in the upper lanes
+__device__ __forceinline__ void mfma_build_a(int g, i32x2 &a0, i32x2 &a1) {
   int p0, p1;
   split_bf16x3(g, p0, p1);
-  const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)p1, false, false);
-  a0 = i32x4{(int)sw[0], kOnesBf16, 0, 0};  // positions 0..31 of the 64
-  a1 = i32x4{(int)sw[1], kOnesBf16, 0, 0};  // positions 32..63
+  const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)p0, (unsigned)kOnesBf16, false, false);
+  const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)p1, (unsigned)kOneLoBf16, false, false);
+  a0 = i32x2{(int)s0[0], (int)s1[0]};  // positions 0..31 of the 64
+  a1 = i32x2{(int)s0[1], (int)s1[1]};  // positions 32..63
 }
 
 // The block of 32 q with index RB (0..7) inside the level's own 256 positions: every block of p
 // below it in full, and block RB itself along the diagonal, where only q > p exists: the mask
 // tile adds -2^30 to the other entries.
 template <int RB>
-__device__ __forceinline__ void mfma_own_block(const i32x4 &a, const i32x4 (&B)[8], const f32x16 &mask, float (&m)[8]) {
+__device__ __forceinline__ void mfma_own_block(const i32x2 &a, const i32x2 (&B)[8], const f32x16 &mask, float (&m)[8]) {
   mfma_tiles<RB + 1>(a, B, mask, m);
+}
+
+// The 16 tiles of two blocks of 32 q against all 8 blocks of p as ONE pipeline (the second block's
+// first tile is formed while the first block's last is reduced: one fill and one drain per 16 tiles).
+__device__ __forceinline__ void mfma_tiles16(const i32x2 &a0, const i32x2 &a1, const i32x2 (&B)[8], float (&m)[8]) {
+  const f32x16 z = {};
+  f32x16 d = mfma_sums(a0, B[0], z);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    f32x16 dn = d;
+    if (t + 1 < 16) {
+      dn = mfma_sums(t + 1 < 8 ? a0 : a1, B[(t + 1) & 7], z);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_reduce(d, m[t & 7]);
+    __builtin_amdgcn_sched_barrier(0);
+    d = dn;
+  }
+}
+
+// A level's own 256 x 256 positions when all of them exist: its 36 tiles (block rb of q against
+// blocks 0..rb of p, the last one of each along the diagonal) as one pipeline.
+__device__ __forceinline__ constexpr int own_rb(int t) {
+  int rb = 0;
+  while ((rb + 1) * (rb + 2) / 2 <= t) ++rb;
+  return rb;
+}
+__device__ __forceinline__ constexpr int own_pb(int t) { return t - own_rb(t) * (own_rb(t) + 1) / 2; }
+__device__ __forceinline__ void mfma_own_level(const int (&g)[4], const i32x2 (&B)[8], const f32x16 &mask, float (&m)[8]) {
+  const f32x16 z = {};
+  i32x2 a0, a1;  // operands of the two blocks of the run of 64 q being scored, built when its first tile is issued
+  mfma_build_a(g[0], a0, a1);
+  f32x16 d = mfma_sums(a0, B[0], mask);
+#pragma unroll
+  for (int t = 0; t < 36; ++t) {
+    f32x16 dn = d;
+    if (t + 1 < 36) {
+      const int rb = own_rb(t + 1), pb = own_pb(t + 1);
+      if (pb == 0 && (rb & 1) == 0) mfma_build_a(g[rb >> 1], a0, a1);
+      dn = mfma_sums((rb & 1) ? a1 : a0, B[pb], pb == rb ? mask : z);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_reduce(d, m[own_pb(t)]);
+    __builtin_amdgcn_sched_barrier(0);
+    d = dn;
+  }
 }
 
 // One unit with every candidate's sum formed on the matrix cores: sub-run j of chunk c at level w
@@ -534,18 +584,24 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q00 + 64 * r), soff, 0);
   }
   int tn = G[rowlen + qend];  // the constant of the next row
+#ifdef PSA_TRACE
+  unsigned long long tr_top = 0, tr_own = 0, tr_long = 0, tr_t;
+#define PSA_TR(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tr_t; tr_t = n_; }
+  tr_t = __builtin_amdgcn_s_memtime();
+#else
+#define PSA_TR(acc)
+#endif
   for (int i = r0; i < r1; ++i) {
-    i32x4 B[8];
+    i32x2 B[8];
     {
       int f[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) f[r] = Cand<true>::sub(fn[r], tn);
       mfma_build_b(f, B);
     }
-    // operands of the level's own four steps
-    i32x4 A0[4], A1[4];
+    int gown[4];  // this offset's g for the level's own four runs (gn is requested anew below)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) mfma_build_a(gn[k], A0[k], A1[k]);
+    for (int k = 0; k < 4; ++k) gown[k] = gn[k];
     const int grow = soff;  // this offset's row of g
     const int adv = i + 1 < r1 ? step : 0;  // the last offset of the unit requests its own rows again
     soff += step;
@@ -567,14 +623,22 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     // the level's own 256 positions: blocks 0..7 of q against the blocks of p below and at them
 #define PSA_OWN_STEP(K)                                                          \
     if (q00 + 64 * K < qend) {                                                     \
-      mfma_own_block<2 * K>(A0[K], B, mask, m);                                    \
-      if (q00 + 64 * K + 32 < L2) mfma_own_block<2 * K + 1>(A1[K], B, mask, m);    \
+      i32x2 a0, a1;                                                                \
+      mfma_build_a(gown[K], a0, a1);                                               \
+      mfma_own_block<2 * K>(a0, B, mask, m);                                       \
+      if (q00 + 64 * K + 32 < L2) mfma_own_block<2 * K + 1>(a1, B, mask, m);       \
     }
-    PSA_OWN_STEP(0)
-    PSA_OWN_STEP(1)
-    PSA_OWN_STEP(2)
-    PSA_OWN_STEP(3)
+    PSA_TR(tr_top)
+    if (q00 + 224 < L2) {  // all eight blocks of q exist
+      mfma_own_level(gown, B, mask, m);
+    } else {
+      PSA_OWN_STEP(0)
+      PSA_OWN_STEP(1)
+      PSA_OWN_STEP(2)
+      PSA_OWN_STEP(3)
+    }
 #undef PSA_OWN_STEP
+    PSA_TR(tr_own)
     // beyond them every (p, q) pair is a candidate; the row is requested three steps ahead into
     // four registers that take turns (no copies, and a wait only ever covers a load three steps old)
     const f32x16 z = {};
@@ -587,14 +651,21 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
         const int qn = q + 64 * k + 192 < qend ? q + 64 * k + 192 : q + 64 * k;
         g[(k + 3) & 3] = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (qn + lane), grow, 0);
         if (q + 64 * k < qend) {
-          i32x4 a0, a1;
+          i32x2 a0, a1;
           mfma_build_a(g[k], a0, a1);
-          mfma_tiles<8>(a0, B, z, m);
-          if (q + 64 * k + 32 < L2) mfma_tiles<8>(a1, B, z, m);
+          if (q + 64 * k + 32 < L2) mfma_tiles16(a0, a1, B, m);
+          else mfma_tiles<8>(a0, B, z, m);
         }
       }
     }
+    PSA_TR(tr_long)
   }
+#undef PSA_TR
+#ifdef PSA_TRACE
+  if (lane == 0 && (u % 509) == 0)
+    printf("unit %d level %d L2 %d offsets %d: per offset top %llu own %llu long %llu cycles\n", u, w, L2, r1 - r0,
+           tr_top / (r1 - r0), tr_own / (r1 - r0), tr_long / (r1 - r0));
+#endif
   // best fixed-point score of this unit and the smallest p attaining it; lanes l and l + 32 hold
   // maxima of the same column over different rows and enter the reduction as they are
   int bestv = INT_MIN;

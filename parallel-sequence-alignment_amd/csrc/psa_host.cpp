@@ -148,13 +148,13 @@ int64_t mutant_of_nk(int n, int k, int len2) { return row_start(n, len2) + (k - 
 // Predicted cost of one Seq2, in cycles of one SIMD.
 //
 // Enumeration stage: the candidate loop works in tiles of 32 q x 32 p (one matrix instruction
-// and 8 v_max3_f32: 40 cycles of vector issue, about 45 measured with operand building, loads and
-// hazard padding).  Per offset and level (256 positions p) it walks the row of g from the level's
+// and 8 v_max3_f32: about 40 cycles measured with operand building, loads and hazard padding).  Per offset and level (256 positions p) it walks the row of g from the level's
 // first position to the row's end: the level's own 8 blocks of q meet 1, 2, ... 8 blocks of p
 // (the last of each along the diagonal, where half of the tile is not a candidate), every later
 // block of q meets all 8; a row is padded to a multiple of 64 positions, of which the last 32 are
-// skipped when they hold no position of Seq2.  About 300 cycles per (offset, level) go into the
-// operands of p and the first loads.  Tiles per candidate therefore fall with the Seq2 length --
+// skipped when they hold no position of Seq2.  About 1300 cycles per (offset, level) go into the
+// operands of p, the requests for the rows and the lower efficiency of the level's own 36 tiles
+// (fitted to uniform batches of Seq2 of 256 to 8000 characters).  Tiles per candidate therefore fall with the Seq2 length --
 // a split by raw candidate counts gives the rank with the short Seq2 more time than work.
 // Resolve stage alone: one dependent float32 chain step per (offset, position).
 double cost_estimate(int64_t len2, int64_t len1, uint32_t stages) {
@@ -170,7 +170,7 @@ double cost_estimate(int64_t len2, int64_t len1, uint32_t stages) {
       tiles += std::min<int64_t>(rb + 1, 8);
       if (q + 32 < len2) tiles += std::min<int64_t>(rb + 2, 8);
     }
-  return double(S) * (45.0 * double(tiles) + 300.0 * double(levels));
+  return double(S) * (40.0 * double(tiles) + 1300.0 * double(levels));
 }
 
 // Longest-processing-time assignment on the predicted cost of each Seq2.

@@ -12,7 +12,7 @@
 //   4  matrix-core form: one v_mfma_f32_32x32x16_bf16 (32 x 32 sums f[p] + g[q] as a K = 6 product
 //      of bf16 pieces) + 8 v_max3_f32 on its 16 results per lane: 1024 candidates per MFMA
 //   5  as 4 plus the six VALU instructions that split 32 values of g into bf16 pieces, once per 8 MFMAs
-//   6  v_mfma_f32_32x32x16_bf16 alone, back to back
+//   6  v_mfma_f32_32x32x16_bf16 alone, back to back      7, 8  as 6 and 4 with v_mfma_f32_32x32x8_bf16_1k
 // Output: cycles per SIMD per 128 candidates (two candidates x 64 lanes), for 1, 2, 4, 8 waves per SIMD.
 //   hipcc -O3 --offload-arch=gfx950 tools/valu_bench10.hip -o tools/valu_bench10
 #include <hip/hip_runtime.h>
@@ -43,6 +43,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   for (int i = 0; i < 8; ++i) {
     a[i] = (short)(0x3f80 + ((threadIdx.x + i) & 3));  // bf16 values near 1.0
     b[i] = (short)(0x3f80 + ((threadIdx.x * 3 + i) & 3));
+  }
+  typedef __attribute__((ext_vector_type(4))) short frag_ab4;  // 4 bf16: operand of the K = 8 form
+  frag_ab4 a4, b4;
+  for (int i = 0; i < 4; ++i) {
+    a4[i] = a[i];
+    b4[i] = b[i];
   }
   frag_cd d0 = {}, d1 = {};
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -78,6 +84,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     } else if (MODE == 6) {
       d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d0, 0, 0, 0);
       d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d1, 0, 0, 0);
+    } else if (MODE == 7) {
+      d0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, d1, 0, 0, 0);
+    } else if (MODE == 8) {
+      const frag_cd z = {};
+      d0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, z, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) MAX3(acc[i], __float_as_int(d1[2 * i]), __float_as_int(d1[2 * i + 1]));
+      d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(b4, a4, z, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) MAX3(acc[i], __float_as_int(d0[2 * i]), __float_as_int(d0[2 * i + 1]));
     } else {
       // two MFMAs per iteration on two result tiles; the maxima of a tile are taken while the
       // other tile's MFMA executes
@@ -182,5 +197,7 @@ int main() {
   run<4>("4: v_mfma_f32_32x32x16_bf16 + 8 v_max3_f32 per 1024 candidates", d_out, d_g, d_st, 2048);
   run<5>("5: as 4 + 6 split instructions per 8 MFMAs", d_out, d_g, d_st, 2048);
   run<6>("6: v_mfma_f32_32x32x16_bf16 alone", d_out, d_g, d_st, 2048);
+  run<7>("7: v_mfma_f32_32x32x8_bf16_1k alone (two-register operands)", d_out, d_g, d_st, 2048);
+  run<8>("8: v_mfma_f32_32x32x8_bf16_1k + 8 v_max3_f32 per 1024 candidates", d_out, d_g, d_st, 2048);
   return 0;
 }
