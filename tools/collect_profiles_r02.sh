@@ -32,6 +32,15 @@ python3 tools/timeline.py $out/stats 60 95 > $out/${tag}_c2_timeline.txt
 echo stats done
 A="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 B="SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
-true # PMC passes were collected in an earlier run of this script
-true
+if [ -z "$SKIP_PMC" ]; then
+  # one run per counter list (FETCH_SIZE and WRITE_SIZE do not fit one pass), the program directly behind `--`
+  tools/pmc_run.sh ${tag}_c2 "" "$A" "$B" "FETCH_SIZE" "WRITE_SIZE" || exit 1
+  tools/pmc_run.sh ${tag}_c4 "--config c4" "$A" "$B" "FETCH_SIZE" "WRITE_SIZE" || exit 1
+  tools/pmc_run.sh ${tag}_len256 "--config c3 --nseq2 512 --len-lo 256 --len-hi 256 --steps 2 --warmup 1" "$A" "$B" || exit 1
+  tools/pmc_run.sh ${tag}_len4000 "--config c3 --nseq2 64 --len-lo 4000 --len-hi 4000 --steps 2 --warmup 1" "$A" "$B" || exit 1
+fi
+# the resolve chain alone (kernel statistics of resolve-only steps) and the chain micro-benchmark
+tools/prof_resolve.sh ${tag} > $out/${tag}_resolve.log 2>&1 || exit 1
+cp gpurun_out/${tag}_resolve_kernel_stats.csv $out/${tag}_resolve_kernel_stats.csv
+run ${tag}_chain_costs.txt tools/chain_bench
 echo collected
