@@ -152,6 +152,8 @@ def check_record(oracle, seq1, seq2, table, r, stages, s_begin=0, s_end=None):
                 b = (m - 1) * u / (1 - (m - 1) * u) * m * tmax + m * 2.0 ** -(fr + 1)
                 if abs(float(r.score) - r.enum_score * 2.0 ** -fr) > b:
                     bad.append("float32 maximum and fixed-point maximum differ by more than the rounding bound")
+                if r.enum_check != 1:
+                    bad.append("the library's own cross-check of the two stages says %d" % r.enum_check)
                 ef = oracle.enum_score(seq1, seq2, itab, r.offset, r.n, r.k)
                 if (r.enum_score - ef) * 2.0 ** -fr > 2 * b or ef > r.enum_score:
                     bad.append("the float32 winner's fixed-point score is not within 2b of the enumerated maximum")

@@ -72,10 +72,17 @@ typedef struct psa_result {
   int32_t enum_exact;
   int32_t enum_counts[4];
   int32_t status;         /* psa_status of this Seq2 */
-  int32_t reserved;
+  int32_t enum_check;     /* the library's own cross-check of the two stages, see below: 1 agree, -1 disagree, 0 not both run */
   int64_t candidates;     /* (offsets in range) x len2 x (len2-1)/2 */
 } psa_result;
 
+/* enum_check: when a run had both stages, psa_batch_wait compares the two independently computed
+ * maxima of every Seq2 -- the float32 answer `score` (reference arithmetic, P/cudaFunctions.cu:210-220)
+ * and the fixed-point maximum over all enumerated candidates `enum_score` * 2^-enum_frac_bits -- against
+ * the rigorous rounding bound between them: with m = len2 - 2 table entries per candidate, u = 2^-24,
+ * b = (m-1)u / (1 - (m-1)u) * m * max|table entry| + m * 2^-(enum_frac_bits + 1).  They must lie within b
+ * of each other; -1 means they do not, i.e. a defect in one of the two stages.  No counterpart in the
+ * reference, which scores once. */
 typedef struct psa_ctx psa_ctx;     /* one per GPU; holds Seq1 and the table resident in HBM */
 typedef struct psa_batch psa_batch; /* a set of Seq2 resident in HBM, plus work lists and result buffers */
 

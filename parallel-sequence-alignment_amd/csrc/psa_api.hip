@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -78,6 +79,7 @@ struct psa_ctx {
   // the chip issues float add + max3 faster than the integer pair) or int32 with 30-bit values
   // (PSA_ENUM_I32=1, 6 more fractional bits in the fixed-point table).
   bool enum_f32 = true;
+  double table_abs_max = 0.0;  // largest |entry| of the current table
   // Slabs of g rows.  Three: with two, the candidate loops of consecutive passes start as soon as
   // their pre-passes are done, share the GPU, end together, and both slabs wait for their
   // pre-passes while nothing else can run (a tenth of the time on many-pass batches); the third
@@ -159,6 +161,7 @@ struct psa_batch {
   float enum_ms = 0.f, total_ms = 0.f;
   bool ran = false;
   bool pending = false, pending_timed = false, pending_resolve = false;  // a run is enqueued, not yet waited for
+  bool pending_both = false;  // ... with both stages: its records get the cross-check of the two maxima
   bool acc_ready = false;  // the accumulators were reset after the previous run
   Bundle *res = nullptr;   // owns every device and pinned pointer above and the events
   bool upload_in_flight = false;  // the asynchronous upload of the work lists has not been waited for
@@ -297,6 +300,8 @@ int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
     return PSA_ERR_STATE;
   }
   std::memcpy(c->table, table, sizeof c->table);
+  c->table_abs_max = 0.0;
+  for (float x : c->table) c->table_abs_max = std::max(c->table_abs_max, (double)std::fabs(x));
   psa::frac_table_scan(c->table, &c->frac_scan);
   // device copy: transposed to [seq2 code][seq1 code], zero row and column for the padding code
   std::vector<float> t(psa::kDevTable, 0.0f);
@@ -923,6 +928,7 @@ int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
   b->pending_timed = timed;
   // which record kernels this run has: the enumeration side's, the resolve side's, or both
   b->pending_resolve = ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) || !timed;
+  b->pending_both = timed && (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
   return PSA_OK;
 }
 
@@ -973,6 +979,17 @@ int psa_batch_wait(psa_batch *b) {
       if (first && last && hipEventElapsedTime(&ms, first, last) == hipSuccess) b->total_ms = std::max(b->total_ms, ms);
     }
   (void)hipGetLastError();
+  // Cross-check of the two stages (psa.h, enum_check): the float32 maximum and the fixed-point
+  // maximum of every Seq2 are the same quantity up to the rigorous rounding bound b.
+  for (int i = 0; i < b->n; ++i) {
+    psa_result &r = b->h_out[i];
+    r.enum_check = 0;
+    if (!b->pending_both || r.status != PSA_OK || r.enum_frac_bits < 0 || r.n <= 0 || r.enum_n <= 0) continue;
+    const double m = (double)b->desc[(size_t)i].len2 - 2.0, u = std::ldexp(1.0, -24);
+    const double bound = (m - 1.0) * u / (1.0 - (m - 1.0) * u) * m * c->table_abs_max + m * std::ldexp(1.0, -(r.enum_frac_bits + 1));
+    const double diff = std::fabs((double)r.score - std::ldexp((double)r.enum_score, -r.enum_frac_bits));
+    r.enum_check = diff <= bound ? 1 : -1;
+  }
   b->ran = true;
   return PSA_OK;
 }

@@ -262,6 +262,7 @@ int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
   if (!parts || !out || nparts < 1) return PSA_ERR_ARG;
   int bi = -1, be = -1;
   int64_t cand = 0;
+  int check = 1;  // 1 only if every shard that scored offsets passed its own cross-check
   for (int i = 0; i < nparts; ++i) {
     const psa_result &p = parts[i];
     if (p.status != PSA_OK) {
@@ -269,6 +270,7 @@ int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
       return p.status;
     }
     cand += p.candidates;
+    if (p.candidates > 0 && p.enum_check != 1) check = check < 0 || p.enum_check < 0 ? -1 : 0;
     if (p.n > 0) {
       bool better = bi < 0 || p.score > parts[bi].score;
       if (!better && p.score == parts[bi].score) {
@@ -299,6 +301,7 @@ int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
     std::memcpy(out->enum_counts, e.enum_counts, sizeof e.enum_counts);
   }
   out->candidates = cand;
+  out->enum_check = check;  // (maxima of pairs that agree within b agree within b)
   return PSA_OK;
 }
 

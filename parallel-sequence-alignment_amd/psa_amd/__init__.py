@@ -38,7 +38,7 @@ class Result(C.Structure):
                 ("score", C.c_float), ("score_bits", C.c_uint32), ("counts", C.c_int32 * 4),
                 ("enum_n", C.c_int32), ("enum_k", C.c_int32), ("enum_offset", C.c_int32),
                 ("enum_score", C.c_int32), ("enum_frac_bits", C.c_int32), ("enum_exact", C.c_int32),
-                ("enum_counts", C.c_int32 * 4), ("status", C.c_int32), ("reserved", C.c_int32),
+                ("enum_counts", C.c_int32 * 4), ("status", C.c_int32), ("enum_check", C.c_int32),
                 ("candidates", C.c_int64)]
 
     def key(self):
@@ -48,7 +48,7 @@ class Result(C.Structure):
         return (self.enum_n, self.enum_k, self.enum_offset, self.enum_score)
 
     def as_dict(self):
-        d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("counts", "enum_counts", "reserved")}
+        d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("counts", "enum_counts")}
         d["counts"] = list(self.counts)
         d["enum_counts"] = list(self.enum_counts)
         return d

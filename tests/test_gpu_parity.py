@@ -56,6 +56,7 @@ def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=
                 m, u = L2 - 2, 2.0 ** -24
                 b = (m - 1) * u / (1 - (m - 1) * u) * m * float(np.abs(table).max()) + m * 2.0 ** -(fr + 1)
                 assert abs(float(r.score) - r.enum_score * 2.0 ** -fr) <= b, ("maxima apart", i, r.score, r.enum_score, fr, b)
+                assert r.enum_check == 1, ("the library's own cross-check", i, r.enum_check)
                 ef = oracle.enum_score(seq1, seq2, itab, r.offset, r.n, r.k)
                 assert ef <= r.enum_score and (r.enum_score - ef) * 2.0 ** -fr <= 2 * b, ("winner apart", i, ef, r.enum_score)
 
