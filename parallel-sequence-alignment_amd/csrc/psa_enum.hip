@@ -18,19 +18,23 @@
 //                    its own: g_{s+1}[p] = E^s[p] + E^{s-1}[L2] - E^{s-1}[p+1] = f_s[p] + E^{s-1}[L2],
 //                    so a chunk of ns offsets stores ns + 1 rows of g, each with its constant
 //                    (4 bytes per position and offset, against L2/2 candidates each);
-//   psa_enum_wave    the candidate loop.  One wave per (offsets, 256 positions p): f sits
-//                    in 4 vector registers per lane, g arrives through scalar loads (it is
-//                    wave-uniform); no LDS, no barriers, so waves are scheduled one by
-//                    one and the chip stays full to the last unit;
+//   psa_enum_wave_mfma  the candidate loop.  One wave per (offsets, 256 positions p): the sums
+//                    f[p] + g[q] of 32 x 32 candidates are one v_mfma_f32_32x32x8_bf16_1k over
+//                    exact bfloat16 pieces of f and g, the vector ALU takes the maxima (8
+//                    v_max3_f32 per 1024 candidates); no LDS, no barriers, so waves are
+//                    scheduled one by one and the chip stays full to the last unit;
+//   psa_enum_wave    the same loop on the vector ALU alone (f in 4 vector registers per lane, g
+//                    through scalar loads): the int32 form and PSA_ENUM_MFMA=0;
 //   psa_enum_locate  second pass over the few chunks that hold the maximum: smallest q
 //                    and offset for the winning p.
 //
-// Instruction mix (measured on MI355X): adds issue at full rate, every integer or float
-// min/max at half rate, so two candidates are folded into one max3: 2 adds + 1 max3 per
-// two candidates.  The float32 pair (v_add_f32, v_max3_f32) issues about a fifth faster
-// than the int32 pair, and float32 adds integers of at most 24 bits exactly, so the
-// default scale keeps f, g and f + g within 24 bits and the loop runs in float32; the
-// int32 form of the same kernels (30-bit values) is kept behind a switch.
+// Instruction mix of the vector-ALU form (measured on MI355X): adds issue at full rate, every
+// integer or float min/max at half rate, so two candidates are folded into one max3: 2 adds +
+// 1 max3 per two candidates.  The float32 pair (v_add_f32, v_max3_f32) issues about a fifth
+// faster than the int32 pair, and float32 adds integers of at most 24 bits exactly, so the
+// default scale keeps f, g and f + g within 24 bits and the loop runs in float32 -- which is
+// also what lets the matrix cores form the sums exactly; the int32 form (30-bit values) is
+// kept behind a switch.
 #include <stdlib.h>
 
 #include <hip/hip_ext.h>
@@ -530,7 +534,7 @@ __device__ __forceinline__ void mfma_own_level(const int (&g)[4], const i32x2 (&
 // One unit with every candidate's sum formed on the matrix cores: sub-run j of chunk c at level w
 // (positions p in [256 w, 256 w + 256) as 8 blocks of 32; q from 256 w to the end of the row in
 // blocks of 32).  The row of an offset is read through per-lane loads of 64 consecutive values,
-// requested two steps ahead; f of an offset is the next offset's row minus that row's constant.
+// requested three steps ahead; f of an offset is the next offset's row minus that row's constant.
 template <bool STAMP>
 __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const WaveParams &P, int u, int lane) {
   // diagnostic build only: shader cycles and 100 MHz ticks this unit took, summed over all units,
