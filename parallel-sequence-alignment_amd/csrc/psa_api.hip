@@ -829,7 +829,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       // when a retiring workgroup frees two wave slots per SIMD at once.)
       int wpg = b->cap_loops ? 8 : 1;
       if (const char *e = std::getenv("PSA_ENUM_WPG")) wpg = std::max(1, std::min(8, std::atoi(e)));  // tuning aid
-      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
+      PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, mfma_loop, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       sp.last_buf = buf;
       c->slab_reader[buf] = sp.ev_e[buf];
       c->slab_reader_batch[buf] = b;

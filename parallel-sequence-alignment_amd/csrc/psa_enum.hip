@@ -989,12 +989,11 @@ static hipError_t launch_locate_t(const EnumParams &P, int grid, hipStream_t st)
   return debug_sync("psa_enum_locate");
 }
 
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int waves_per_group, int lds_bytes,
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, bool use_mfma, int waves_per_group, int lds_bytes,
                             hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (waves_per_group < 1 || waves_per_group > 8) return hipErrorInvalidValue;
   const dim3 grid((P.nunits + waves_per_group - 1) / waves_per_group), block(64 * waves_per_group);
   // the events ride on the kernel's own dispatch packet: no marker packets before or after it
-  static const bool use_mfma = !(getenv("PSA_ENUM_MFMA") && atoi(getenv("PSA_ENUM_MFMA")) == 0);  // tuning aid
   if (f32 && use_mfma && P.clock_probe)
     hipExtLaunchKernelGGL(psa_enum_wave_mfma<true>, grid, block, lds_bytes, st, ev_start, ev_stop, 0, fg, P);
   else if (f32 && use_mfma)

@@ -91,7 +91,8 @@ hipError_t launch_setup_small(const void *src, void *dst, size_t bytes, SeqAcc *
 hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
                             hipEvent_t ev_stop);
 // (workgroups of waves_per_group waves, 1 to 8, one unit per wave; lds_bytes are requested per workgroup and never touched)
-hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, int waves_per_group, int lds_bytes,
+// (use_mfma: the matrix-core form of the loop, float32 only; else the vector-ALU form)
+hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, bool use_mfma, int waves_per_group, int lds_bytes,
                             hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st);
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,

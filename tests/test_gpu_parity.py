@@ -189,6 +189,23 @@ def test_enum_int32_arithmetic(psa, oracle, monkeypatch):
     c.close()
 
 
+def test_enum_vector_alu_form(psa, oracle, monkeypatch):
+    """PSA_ENUM_MFMA=0 when a batch is created: its candidate loop runs on the vector ALU (the form
+    the int32 arithmetic uses) and returns the records of the matrix-core loop."""
+    seq1, seq2s = synth_problem(9, 2300, [64, 65, 300, 511, 1025, 2000])
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    matrix = c.score_batch(seq2s)
+    check_against_oracle(oracle, seq1, seq2s, oracle.comp_matrix(w), matrix)
+    monkeypatch.setenv("PSA_ENUM_MFMA", "0")
+    vector = c.score_batch(seq2s)
+    monkeypatch.delenv("PSA_ENUM_MFMA")
+    assert [bytes(r) for r in vector] == [bytes(r) for r in matrix]
+    c.close()
+
+
 def test_runs_back_to_back_alternate(psa, oracle, monkeypatch):
     """Seven runs of one resident batch enqueued at once (consecutive candidate loops alternate
     between two streams, two slabs and two copies of the accumulators and overlap), for a one-pass
