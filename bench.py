@@ -504,6 +504,9 @@ def roofline_block(cfg, w):
         # the same in the matrix instruction's own flops (32 x 32 x 8 x 2 per 1024 candidates): half the bf16
         # dense peak of the chip, because the K = 8 form does half the K = 16 form's products in the same 32 cycles
         "achieved_tflops": achieved * 16.0 / 1e12, "peak_tflops": PEAK_CANDIDATES * 16.0 / 1e12,
+        # for reference only: against the chip's bf16 dense matrix peak (2.5 PFLOP/s, K = 16 forms); of the 16 flops
+        # per candidate 6 multiply a piece by one and carry the sum, the rest multiply zeros
+        "frac_of_bf16_dense_peak": achieved * 16.0 / 2.5e15,
         # the same with the whole step in the denominator (pre-pass, locate, records and every gap included)
         "step_frac": cand_rank * steps / my_elapsed / PEAK_CANDIDATES,
         # clock the chip held under this kernel (its waves' shader cycles / 100 MHz ticks, measured by this run)
