@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "parallel-sequence-alignment_amd"))
 import bench, psa_amd
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
-_, seq1, seq2s, _ = bench.make_workload(cfg, 0, 1, 0)
+seq1, seq2s = bench.synth(2, 3000, [2000] * 4) if cfg == 'c2' else bench.synth(3, 1489, [138, 1202, 466, 377])
 ctx = psa_amd.Context(0)
 ctx.set_seq1(seq1)
 ctx.set_weights(bench.WEIGHTS)
