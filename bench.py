@@ -159,7 +159,7 @@ def check_record(oracle, seq1, seq2, table, r, stages, s_begin=0, s_end=None):
                 b = (m - 1) * u / (1 - (m - 1) * u) * m * tmax + m * 2.0 ** -(fr + 1)
                 if abs(float(r.score) - r.enum_score * 2.0 ** -fr) > b:
                     bad.append("float32 maximum and fixed-point maximum differ by more than the rounding bound")
-                if r.enum_check != 1:
+                if r.enum_check not in (1, 2):  # 2: the replayed shortlist gave this very record; 1: it overflowed
                     bad.append("the library's own cross-check of the two stages says %d" % r.enum_check)
                 ef = oracle.enum_score(seq1, seq2, itab, r.offset, r.n, r.k)
                 if (r.enum_score - ef) * 2.0 ** -fr > 2 * b or ef > r.enum_score:
@@ -567,6 +567,16 @@ def host_inclusive(ctx, seq1, seq2s, calls=20):
     return out
 
 
+def shortlist_stats(records):
+    """How the records' answers are tied to the enumerated candidates: enum_check 2 = the float32 replay of the
+    shortlisted candidates (those within the rounding window of the enumerated maximum) returned this very record,
+    1 = the shortlist was given up (too many near-maximal candidates) and only the rounding bound was checked."""
+    recs = [r for r in records if r is not None and r.status == 0 and r.candidates > 0]
+    return {"records": len(recs), "replay_equals_answer": sum(1 for r in recs if r.enum_check == 2),
+            "bound_only": sum(1 for r in recs if r.enum_check == 1),
+            "other": sum(1 for r in recs if r.enum_check not in (1, 2))}
+
+
 def scale_entry(w, world):
     """The strong-scaling figures of one workload of the scale block."""
     return {"workload": w["name"], "scaling": w["scaling"], "value": w["cand_total"] * w["steps"] / w["elapsed"],
@@ -577,6 +587,7 @@ def scale_entry(w, world):
             "per_rank_ms_per_step": [1e3 * p[0] / w["steps"] for p in w["per_rank"]],
             "imbalance_max_over_mean": max(p[0] for p in w["per_rank"]) / (sum(p[0] for p in w["per_rank"]) / world),
             "parity": w["parity"], "parity_checked_records": w["parity_checked"],
+            "shortlist": shortlist_stats(w["answer"]) if w["stages"] == 3 else None,
             "result_sample": {"n": w["answer"][0].n, "k": w["answer"][0].k, "offset": w["answer"][0].offset,
                               "score_bits": "0x%08x" % w["answer"][0].score_bits} if w["answer"] else None}
 
@@ -647,7 +658,8 @@ def main():
             if args.config != "c1" else "reference sample input",
             "parity": parity,
             "parity_detail": {"records_checked_against_oracle": w["parity_checked"] * (world if args.config in ("c1", "c2") else 1),
-                              "complaints": w["complaints"][:5]},
+                              "complaints": w["complaints"][:5],
+                              "shortlist": shortlist_stats(w["answer"]) if w["stages"] == 3 else None},
             "config": {"workload": w["name"], "stages": args.stages, "weights": [float(x) for x in WEIGHTS],
                        "candidates_per_step": w["cand_total"], "prewarm_s": args.prewarm_s,
                        "per_rank_ms_per_step": [1e3 * p[0] / w["steps"] for p in w["per_rank"]]},

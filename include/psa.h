@@ -72,7 +72,7 @@ typedef struct psa_result {
   int32_t enum_exact;
   int32_t enum_counts[4];
   int32_t status;         /* psa_status of this Seq2 */
-  int32_t enum_check;     /* the library's own cross-check of the two stages, see below: 1 agree, -1 disagree, 0 not both run */
+  int32_t enum_check;     /* the library's own cross-check of the two stages, see below: 2 or 1 agree, negative disagree, 0 not both run */
   int64_t candidates;     /* (offsets in range) x len2 x (len2-1)/2 */
 } psa_result;
 
@@ -82,7 +82,20 @@ typedef struct psa_result {
  * the rigorous rounding bound between them: with m = len2 - 2 table entries per candidate, u = 2^-24,
  * b = (m-1)u / (1 - (m-1)u) * m * max|table entry| + m * 2^-(enum_frac_bits + 1).  They must lie within b
  * of each other; -1 means they do not, i.e. a defect in one of the two stages.  No counterpart in the
- * reference, which scores once. */
+ * reference, which scores once.
+ *
+ * The shortlist.  The candidate the reference reports has a fixed-point score within 2b of the enumerated
+ * maximum, so an enumerating run collects every candidate inside that window (per Seq2 up to a capacity of
+ * 256 to 8192 entries, depending on the batch size) and replays each one in float32 exactly as
+ * calcMutantScore adds it (P/cudaFunctions.cu:210-220); the replayed winner -- highest score, ties to the
+ * smallest (n, k, offset) -- is then the reference's answer, obtained from the enumerated candidates alone.
+ *   - Run with both stages: enum_check = 2 when that winner equals the resolve stage's record bit for bit
+ *     (score bits, n, k, offset), -2 when it does not (a defect), and stays 1 when the list overflowed
+ *     (low-entropy inputs can put millions of candidates inside the window) -- the bound above still holds.
+ *   - Run with PSA_STAGE_ENUMERATE alone: n, k, offset, mutant_num, score, score_bits and counts are filled
+ *     from the replayed winner when the list is complete, and stay 0 when it overflowed (run the resolve
+ *     stage then); psa_batch_shortlist tells which.
+ * PSA_SHORTLIST=0 in the environment of psa_init switches the shortlist off. */
 typedef struct psa_ctx psa_ctx;     /* one per GPU; holds Seq1 and the table resident in HBM */
 typedef struct psa_batch psa_batch; /* a set of Seq2 resident in HBM, plus work lists and result buffers */
 
@@ -148,6 +161,10 @@ int psa_batch_results(const psa_batch *b, psa_result *out);
  * the time during which a candidate-loop kernel of the enumeration stage was executing (passes of a
  * large batch overlap), and first kernel start to last kernel end */
 int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms);
+/* per Seq2 of the last run: entries of its shortlist (see enum_check) and the list's state -- 0 no shortlist
+ * (stage not run, switched off, invalid Seq2), 1 complete and replayed, 2 overflowed.  Either array may be
+ * NULL.  No counterpart in the reference. */
+int psa_batch_shortlist(const psa_batch *b, int32_t *count, int32_t *state);
 int psa_batch_size(const psa_batch *b);
 void psa_batch_destroy(psa_batch *b);
 

@@ -102,6 +102,7 @@ struct psa_ctx {
   std::vector<Bundle *> spare;         // bundles of destroyed batches
   unsigned long long *d_probe = nullptr;  // clock probe of the candidate loop: cycles, 100 MHz ticks, units
   bool probe_on = false;
+  bool shortlist = true;  // enumerating runs shortlist and replay the candidates near the maximum (PSA_SHORTLIST=0: off)
   // Batches created on this context and not yet destroyed.  A batch keeps values derived from
   // Seq1 and the table (offset ranges, forward blocks, the fixed-point scale), so neither may be
   // replaced while one exists; psa_shutdown detaches the ones a caller left behind.
@@ -143,6 +144,12 @@ struct psa_batch {
   psa::ActiveOffset *d_active = nullptr;
   psa_result *h_out = nullptr;  // pinned and mapped: psa_finalize writes the records straight into it
   psa_result *d_out = nullptr;  // the device's address of h_out
+  // shortlists of the enumeration stage (psa_internal.h): short_cap entries per Seq2, two copies like the
+  // accumulators; what the record kernel reports of them lands beside the records
+  psa::ShortRow *d_short = nullptr;
+  int short_cap = 0;  // rows of one copy of the list
+  psa::ShortOut *h_short = nullptr, *d_short_out = nullptr;
+  bool pending_short = false;  // the enqueued run fills h_short
   // start of the first / end of the last kernel on the enumeration side and on the resolve side
   hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_res_first = nullptr, ev_res = nullptr, ev_init = nullptr;
   hipEvent_t ev_upload = nullptr;  // the work lists have arrived on the device
@@ -207,6 +214,7 @@ int psa_init(int device, psa_ctx **out) {
   PSA_HIP_C(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = std::getenv("PSA_ENUM_I32")) c->enum_f32 = std::atoi(e) == 0;
+  if (const char *e = std::getenv("PSA_SHORTLIST")) c->shortlist = std::atoi(e) != 0;
   // dynamic-LDS limits of the kernels: an attribute of (kernel, device), so set per context
   PSA_HIP_C(psa::set_enum_kernel_attributes());
   PSA_HIP_C(psa::set_resolve_kernel_attributes());
@@ -433,6 +441,18 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     if (psa::enum_class_of((int)L2) < 0) d.frac_bits = -1;
     r.enum_frac_bits = d.frac_bits;
     r.enum_exact = d.frac_bits >= 0 ? exact : -1;
+    d.enum_slack = -1;
+    if (d.frac_bits >= 0 && c->shortlist && (stages & PSA_STAGE_ENUMERATE)) {
+      // Window of the shortlist: for one candidate of m table entries |fl(sum) - E 2^-r| <= bnd, so the
+      // candidate with the highest float32 sum has E >= (enumerated maximum) - 2 bnd 2^r.  The float32 term
+      // vanishes when every partial sum is exact (level 2), the table term when the table is (level >= 1).
+      const double m = (double)(L2 - 2), u = std::ldexp(1.0, -24);
+      double bnd = 0.0;
+      if (exact < 2 && m > 1.0) bnd += (m - 1.0) * u / (1.0 - (m - 1.0) * u) * m * c->table_abs_max;
+      if (exact < 1) bnd += m * std::ldexp(1.0, -(d.frac_bits + 1));
+      const double units = 2.0 * std::ldexp(bnd, d.frac_bits);
+      if (units < (double)(1 << 28)) d.enum_slack = bnd > 0.0 ? (int32_t)units + 1 : 0;
+    }
     r.candidates = (se - sb) * (L2 * (L2 - 1) / 2);
     r.status = PSA_OK;
     b->max_len2 = std::max<int>(b->max_len2, (int)L2);
@@ -622,9 +642,21 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   const size_t o_cnt = align_up(o_acc + 2 * (size_t)n * sizeof(psa::SeqAcc), 256);
   const size_t o_fs = align_up(o_cnt + 64, 256);
   const size_t o_active = align_up(o_fs + (size_t)fs_total * sizeof(float), 256);
-  const size_t dev_bytes = align_up(o_active + (size_t)fs_total * sizeof(psa::ActiveOffset), 256) + 256;
+  // The shortlist of a run: room for every Seq2's full quota of rows up to a million rows (24 MB), so that
+  // below that a record does not depend on what else its batch holds (a list split over ranks returns the
+  // records of the whole list); beyond it a batch of mostly low-entropy Seq2 can fill the list, and the Seq2
+  // that find it full are given up like those over their own quota.
+  int short_cap = 0;
+  if (c->shortlist && !chunks.empty()) {
+    short_cap = (int)std::min<int64_t>((int64_t)std::max(1, b->nvalid) * psa::kShortRowsPerSeq, 1 << 20);
+    if (const char *e = std::getenv("PSA_SHORT_ROWS")) short_cap = std::max(1, std::min(1 << 20, std::atoi(e)));  // test aid
+  }
+  b->short_cap = short_cap;
+  const size_t o_short = align_up(o_active + (size_t)fs_total * sizeof(psa::ActiveOffset), 256);
+  const size_t dev_bytes = align_up(o_short + 2 * (size_t)short_cap * sizeof(psa::ShortRow), 256) + 256;
   const size_t o_out = upload_bytes;  // in the pinned block the records follow the staging area
-  const size_t pin_bytes = o_out + std::max<size_t>(1, (size_t)n) * sizeof(psa_result);
+  const size_t o_sout = align_up(o_out + std::max<size_t>(1, (size_t)n) * sizeof(psa_result), 64);
+  const size_t pin_bytes = o_sout + std::max<size_t>(1, (size_t)n) * sizeof(psa::ShortOut);
   {
     Bundle *u = nullptr;
     for (size_t i = 0; i < c->spare.size(); ++i)
@@ -693,6 +725,10 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     b->h_out = (psa_result *)(u->pin + o_out);
     if (n > 0) std::memcpy(b->h_out, b->tmpl.data(), (size_t)n * sizeof(psa_result));
     b->d_out = (psa_result *)(u->pin_dev + o_out);
+    b->d_short = short_cap > 0 ? (psa::ShortRow *)(u->dev + o_short) : nullptr;
+    b->h_short = (psa::ShortOut *)(u->pin + o_sout);
+    b->d_short_out = (psa::ShortOut *)(u->pin_dev + o_sout);
+    if (n > 0) std::memset(b->h_short, 0, (size_t)n * sizeof(psa::ShortOut));
     b->ev_first = u->ev[0];
     b->ev_last = u->ev[1];
     b->ev_init = u->ev[2];
@@ -738,12 +774,12 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   if (init) {
     // on st_res, which never waits for a candidate loop
     if (b->setup_src) {
-      PSA_HIP(psa::launch_setup_small(b->setup_src, b->d_pool, b->setup_bytes, b->d_acc, 2 * b->n, b->d_counters, 1,
+      PSA_HIP(psa::launch_setup_small(b->setup_src, b->d_pool, b->setup_bytes, b->d_acc, 2 * b->n, b->d_counters, 3,
                                       b->d_chunk_best, 2 * (size_t)b->nchunks, c->st_res));
       PSA_HIP(psa::debug_sync("psa_setup_small"));
     } else {
       if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_upload, 0));
-      PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 1, c->st_res));
+      PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 3, c->st_res));
       PSA_HIP(psa::debug_sync("psa_init_acc"));
       if (b->nchunks > 0)
         PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, 2 * (size_t)b->nchunks * sizeof(unsigned long long), c->st_res));
@@ -777,6 +813,11 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.desc = b->d_desc;
     P.acc = eacc;
     P.table_t = c->d_table_t;
+    P.short_rows = b->d_short ? b->d_short + (size_t)par * (size_t)b->short_cap : nullptr;
+    P.short_total = b->d_short ? b->d_counters + 1 + par : nullptr;
+    P.short_rows_cap = b->short_cap;
+    F.short_total = P.short_total;
+    F.short_out = b->d_short_out;
     // A pre-pass may fill a slab as soon as the last candidate loop that read it has finished,
     // so it runs beside the candidate loop of the pass before it (on the other slab) and, for
     // runs enqueued back to back, beside the candidate loop of the run before.
@@ -859,6 +900,20 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       const int grid = std::min({c1 - c0, std::max(64, (c1 - c0) / 16), 4 * c->num_cus});
       PSA_HIP(psa::launch_enum_locate(cls, P, grid, st_tail));
     }
+    if (P.short_rows) {
+      psa::ResolveParams R{};
+      R.seq1 = c->d_seq1;
+      R.len1 = c->len1;
+      R.seq2_pool = b->d_pool;
+      R.desc = b->d_desc;
+      R.table_t = c->d_table_t;
+      R.pchunks = (b->max_len2 + 255) / 256;
+      R.short_rows = P.short_rows;
+      R.short_total = P.short_total;
+      R.short_rows_cap = P.short_rows_cap;
+      R.eacc = eacc;
+      PSA_HIP(psa::launch_short_replay(R, b->max_len2, std::max(256, std::min(4096, b->nvalid * R.pchunks * 8)), st_tail));
+    }
     F.which = resolve ? PSA_STAGE_ENUMERATE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
     b->ev_last = b->ev_tail[par];
     PSA_HIP(psa::launch_finalize(F, b->n, st_tail, nullptr, b->ev_last));
@@ -932,6 +987,7 @@ int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
   // which record kernels this run has: the enumeration side's, the resolve side's, or both
   b->pending_resolve = ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) || !timed;
   b->pending_both = timed && (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
+  b->pending_short = timed && b->d_short != nullptr;
   return PSA_OK;
 }
 
@@ -993,6 +1049,25 @@ int psa_batch_wait(psa_batch *b) {
     const double diff = std::fabs((double)r.score - std::ldexp((double)r.enum_score, -r.enum_frac_bits));
     r.enum_check = diff <= bound ? 1 : -1;
   }
+  // The replayed shortlist (psa.h): in a run with both stages its winner must BE the float32 answer; a run of
+  // the enumeration stage alone takes its answer from it.
+  for (int i = 0; i < b->n && b->pending_short; ++i) {
+    psa_result &r = b->h_out[i];
+    const psa::ShortOut &so = b->h_short[i];
+    if (r.status != PSA_OK || so.state != 1) continue;
+    if (b->pending_both) {
+      if (r.enum_check == 1)
+        r.enum_check = (so.score_bits == r.score_bits && so.n == r.n && so.k == r.k && so.offset == r.offset) ? 2 : -2;
+    } else {
+      r.n = so.n;
+      r.k = so.k;
+      r.offset = so.offset;
+      r.score_bits = so.score_bits;
+      std::memcpy(&r.score, &so.score_bits, sizeof(float));
+      r.mutant_num = (int32_t)(psa::mutant_of_nk(so.n, so.k, b->desc[(size_t)i].len2) - 1);
+      for (int k = 0; k < 4; ++k) r.counts[k] = so.counts[k];
+    }
+  }
   b->ran = true;
   return PSA_OK;
 }
@@ -1006,6 +1081,17 @@ int psa_batch_results(const psa_batch *b, psa_result *out) {
   if (!b || (!out && b->n > 0)) return PSA_ERR_ARG;
   if (!b->ctx || !b->ran) return PSA_ERR_STATE;
   if (b->n > 0) std::memcpy(out, b->h_out, (size_t)b->n * sizeof(psa_result));
+  return PSA_OK;
+}
+
+int psa_batch_shortlist(const psa_batch *b, int32_t *count, int32_t *state) {
+  if (!b) return PSA_ERR_ARG;
+  if (!b->ctx || !b->ran) return PSA_ERR_STATE;
+  for (int i = 0; i < b->n; ++i) {
+    const bool have = b->pending_short && b->h_out[i].status == PSA_OK;
+    if (count) count[i] = have ? b->h_short[i].count : 0;
+    if (state) state[i] = have ? b->h_short[i].state : 0;
+  }
   return PSA_OK;
 }
 

@@ -65,6 +65,8 @@ __device__ __forceinline__ SeqDesc load_desc(const SeqDesc *p) {
   d.s_end = uni(p->s_end);
   d.frac_bits = uni(p->frac_bits);
   d.enum_ns = uni(p->enum_ns);
+  d.enum_slack = uni(p->enum_slack);
+  d.pad_ = 0;
   return d;
 }
 

@@ -53,7 +53,10 @@ struct EnumLds {
   static constexpr int wtot = itab + kDevTable * 4;  // 16 int32
   static constexpr int red = wtot + 16 * 4;          // 16 u64
   static constexpr int awin = red + 16 * 8;          // kEnumMaxNs + NP + 2 bytes, rounded up
-  static constexpr int total = awin + ((kEnumMaxNs + NP + 2 + 15) / 16) * 16;
+  // shortlist pass of the locate kernel: 16 wave maxima of f, a counter and a flag, kShortPList positions
+  // and as many masks, the maxima of g per run of 64 positions (at most 128) and their suffix maxima
+  static constexpr int slist = awin + ((kEnumMaxNs + NP + 2 + 15) / 16) * 16;
+  static constexpr int total = slist + (32 + 4 + 2 * kShortPList + 256) * 4;
 };
 
 // Exclusive prefix sums of one diagonal into ring slot (delta mod 3).
@@ -882,24 +885,56 @@ __global__ __launch_bounds__(512, 4) void psa_enum_wave_mfma(const int *__restri
 // waves per SIMD the locate kernel's register budget is sized for
 constexpr int enum_waves_per_simd(int nt, int r) { return nt * r > 4096 ? 4 : 8; }
 
-// Second pass: knowing the maximum G and the smallest p* that attains it, find the
-// smallest q and then the smallest offset with f_s[p*] + g_s[q] == G.  Only chunks
-// whose own (maximum, p) equals the Seq2's can contain such a candidate.
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+  return v;
+}
+
+// Second pass, two jobs on the chunks worth revisiting (nearly every chunk is skipped after three
+// loads):
+// * locate: knowing the maximum G and the smallest p* that attains it, find the smallest q and
+//   then the smallest offset with f_s[p*] + g_s[q] == G.  Only chunks whose own (maximum, p)
+//   equals the Seq2's can contain such a candidate.
+// * shortlist: every (offset, p) that has a candidate with f_s[p] + g_s[q] >= G - slack becomes a
+//   row of the run's list, with the mask of the 256-wide blocks of q that hold one, to be replayed
+//   in float32 (launch_short_replay).  Only chunks whose maximum reaches that window can hold
+//   one.  Per offset the block takes the maxima of f and of g (an offset whose two maxima do not
+//   add up to the window is done), lists the positions p that could reach the window with the
+//   best g behind them, and walks the row of g once per listed p.  A Seq2 with more rows than
+//   kShortRowsPerSeq is given up (its counter stays above that): on a low-entropy input every
+//   row can lie inside the window.
 template <int NT, int R>
 __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locate(EnumParams P) {
   using L = EnumLds<NT, R>;
   constexpr int NW = NT / 64;
+  constexpr int kNone = -(1 << 29);  // below every f and g; two of them still add up inside int32
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   unsigned long long *red = (unsigned long long *)(smem + L::red);
+  int *wmax = (int *)(smem + L::slist);  // [0,16): f
+  int *plist_n = wmax + 32;  // [0] positions listed, [1] the Seq2 has been given up
+  int *plist = wmax + 36;
+  unsigned *pmask = (unsigned *)(plist + kShortPList);
+  int *bg = (int *)(pmask + kShortPList);  // max of g over positions [64 i, 64 i + 64)
+  int *sg = bg + 128;                      // max of g over positions >= 64 i
+  constexpr int NB = R * NW;
+  static_assert(NB <= 128, "two values per lane in the suffix scan");
+  constexpr unsigned cap = (unsigned)kShortRowsPerSeq;
 
   for (int c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
     const Chunk ch = load_chunk(P.chunks + c);
     const unsigned long long ek = P.acc[ch.seq].enum_key;
     const unsigned long long ck = P.chunk_best[c];
+    const int G = uni((int)((uint32_t)(ek >> 32) ^ 0x80000000u));
+    int slack = -1;
+    if (P.short_rows) slack = uni(P.desc[ch.seq].enum_slack);
     // This kernel is the last reader of chunk_best in a run and leaves it zeroed for the next.
-    // A wave that reads the zero instead of ck takes the same branch: ek is never 0.
-    if (uni((int)(ek != ck))) {
+    // A wave that reads the zero instead of ck takes the same branch: ek is never 0, and the
+    // zero decodes to the lowest value, outside every window.
+    const bool exact = uni((int)(ek == ck));
+    bool near = uni((int)(slack >= 0 && (int)((uint32_t)(ck >> 32) ^ 0x80000000u) >= G - slack));
+    if (!exact && !near) {
       if (tid == 0) P.chunk_best[c] = 0ull;
       continue;
     }
@@ -910,8 +945,9 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
     __syncthreads();
     if (tid == 0) P.chunk_best[c] = 0ull;
     enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
-    const int G = uni((int)((uint32_t)(ek >> 32) ^ 0x80000000u));
     const int pstar = uni((int)(0xffffffffu - (uint32_t)ek));
+    const int T = G - slack;
+    unsigned *const scount = &P.acc[ch.seq].short_count;
     unsigned long long best = ~0ull;
     for (int s = ch.s0; s < ch.s0 + ch.ns; ++s) {
       scan_diagonal<NT, R>(smem, bro, s, win0);
@@ -919,25 +955,121 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
       const int *E1 = ring_slot<NT, R>(smem, s - 1);
       const int *E2 = ring_slot<NT, R>(smem, s - 2);
       const int tot2 = E2[L2];
-      const int fstar = Es[pstar] - E1[pstar + 1];
+      if (exact) {
+        const int fstar = Es[pstar] - E1[pstar + 1];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int q = r * NT + tid;
-        if (q > pstar && q <= L2 - 1) {
-          int gq = E1[q] + tot2 - E2[q + 1];
-          if (fstar + gq == G) {
-            unsigned long long k = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)s;
-            best = k < best ? k : best;
+        for (int r = 0; r < R; ++r) {
+          const int q = r * NT + tid;
+          if (q > pstar && q <= L2 - 1) {
+            int gq = E1[q] + tot2 - E2[q + 1];
+            if (fstar + gq == G) {
+              unsigned long long k = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)s;
+              best = k < best ? k : best;
+            }
           }
         }
       }
+      if (near) {
+        int gq[R];
+        int mf = kNone;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int x = r * NT + tid;
+          gq[r] = (x >= 1 && x <= L2 - 1) ? E1[x] + tot2 - E2[x + 1] : kNone;
+          const int fx = x <= L2 - 2 ? Es[x] - E1[x + 1] : kNone;
+          mf = max(mf, fx);
+          const int wg = wave_max_i32(gq[r]);
+          if (lane == 0) bg[r * NW + w] = wg;
+        }
+        mf = wave_max_i32(mf);
+        if (lane == 0) wmax[w] = mf;
+        if (tid == 0) {
+          *plist_n = 0;
+          // whether the list has overflowed meanwhile is read by one thread: the waves of the block
+          // must agree on it, there are barriers behind the decision
+          plist_n[1] = __atomic_load_n(scount, __ATOMIC_RELAXED) > cap;
+        }
+        __syncthreads();
+        if (uni(plist_n[1])) near = false;
+        if (w == 0) {  // suffix maxima of the runs' maxima: position p can only pair with a q behind it
+          int v0 = lane < NB ? bg[lane] : kNone, v1 = 64 + lane < NB ? bg[64 + lane] : kNone;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int t0 = __shfl_down(v0, o), t1 = __shfl_down(v1, o);
+            if (lane + o < 64) {
+              v0 = max(v0, t0);
+              v1 = max(v1, t1);
+            }
+          }
+          v0 = max(v0, __shfl(v1, 0));
+          sg[lane] = v0;
+          sg[64 + lane] = v1;
+        }
+        __syncthreads();
+        int MF = wmax[0];
+        for (int i = 1; i < NW; ++i) MF = max(MF, wmax[i]);
+        if (uni((int)(near && MF + sg[0] >= T))) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int x = r * NT + tid;
+            const int fx = x <= L2 - 2 ? Es[x] - E1[x + 1] : kNone;
+            // (against the best g from the start of x's own run of 64 on: a few positions too many)
+            if (fx + sg[r * NW + w] >= T) {
+              const int k = atomicAdd(plist_n, 1);
+              if (k < kShortPList) plist[k] = x;
+            }
+          }
+          for (int k = tid; k < kShortPList; k += NT) pmask[k] = 0u;
+          __syncthreads();
+          int np = *plist_n;
+          if (np > kShortPList) {  // more positions than the list holds: give this Seq2 up
+            if (tid == 0) atomicMax(scount, cap + 1u);
+            np = 0;
+          }
+          for (int k = 0; k < np; ++k) {
+            const int p = plist[k];
+            const int fp = Es[p] - E1[p + 1];
+            unsigned mask = 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int q = r * NT + tid;
+              if (q > p && fp + gq[r] >= T) mask |= 1u << (q >> 8);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) mask |= (unsigned)__shfl_xor((int)mask, m);
+            if (lane == 0 && mask) atomicOr(&pmask[k], mask);
+          }
+          __syncthreads();
+          for (int k = tid; k < np; k += NT) {
+            const unsigned mask = pmask[k];
+            if (!mask) continue;  // the best g lies at or before p
+            if (atomicAdd(scount, 1u) >= cap) continue;
+            const unsigned idx = atomicAdd(P.short_total, 1u);
+            if (idx < (unsigned)P.short_rows_cap) {
+              ShortRow row;
+              row.seq = ch.seq;
+              row.s = s;
+              row.p = (uint32_t)plist[k];
+              row.qmask = mask;
+              row.best = 0ull;
+              P.short_rows[idx] = row;
+            } else {
+              atomicMax(scount, cap + 1u);  // the run's list is full
+            }
+          }
+          // (the next offset's scan has barriers between these reads of the list and its reset)
+        }
+      }
+      if (!near && !exact) break;
     }
-    best = wave_min_u64(best);
-    if (lane == 0) red[w] = best;
-    __syncthreads();
-    if (tid == 0) {
-      for (int i = 1; i < NW; ++i) best = red[i] < best ? red[i] : best;
-      if (best != ~0ull) atomicMin(&P.acc[ch.seq].enum_loc, best);
+    if (exact) {
+      best = wave_min_u64(best);
+      if (lane == 0) red[w] = best;
+      __syncthreads();
+      if (tid == 0) {
+        for (int i = 1; i < NW; ++i) best = red[i] < best ? red[i] : best;
+        if (best != ~0ull) atomicMin(&P.acc[ch.seq].enum_loc, best);
+      }
     }
   }
 }

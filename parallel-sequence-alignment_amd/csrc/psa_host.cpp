@@ -262,7 +262,10 @@ int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
   if (!parts || !out || nparts < 1) return PSA_ERR_ARG;
   int bi = -1, be = -1;
   int64_t cand = 0;
-  int check = 1;  // 1 only if every shard that scored offsets passed its own cross-check
+  // the weakest cross-check of the shards that scored offsets: 2 (every shard's replayed shortlist gave its
+  // float32 answer, so the best of those is the combined answer), 1 (bound only), 0 (some shard ran one
+  // stage), negative (some shard failed)
+  int check = 2;
   for (int i = 0; i < nparts; ++i) {
     const psa_result &p = parts[i];
     if (p.status != PSA_OK) {
@@ -270,7 +273,7 @@ int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
       return p.status;
     }
     cand += p.candidates;
-    if (p.candidates > 0 && p.enum_check != 1) check = check < 0 || p.enum_check < 0 ? -1 : 0;
+    if (p.candidates > 0) check = (check < 0 || p.enum_check < 0) ? std::min(std::min(check, (int)p.enum_check), -1) : std::min(check, (int)p.enum_check);
     if (p.n > 0) {
       bool better = bi < 0 || p.score > parts[bi].score;
       if (!better && p.score == parts[bi].score) {

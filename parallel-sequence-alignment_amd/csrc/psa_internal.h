@@ -25,6 +25,8 @@ struct SeqDesc {
   int32_t s_end;
   int32_t frac_bits;  // fixed-point scale of the enumeration stage, -1 = stage off for this Seq2
   int32_t enum_ns;    // offsets one wave of the enumeration kernel walks (a sub-run of a chunk)
+  int32_t enum_slack; // shortlist window below the enumerated maximum in fixed-point units, -1 = no shortlist
+  int32_t pad_;
 };
 
 // Per-Seq2 accumulators the kernels reduce into with 64/32-bit atomics.
@@ -34,7 +36,35 @@ struct SeqAcc {
   unsigned long long res_loc;   // min of (q << 32 | offset) for the float32 path
   uint32_t res_key;             // max of the order-preserving image of the float32 score
   int32_t res_p;                // min p attaining the float32 maximum
+  unsigned long long short_best;  // shortlist: max of (float32 score image << 32 | ~p << 16 | ~q) over the replayed rows
+  uint32_t short_s;             // ... and the smallest offset among the rows that attain it
+  uint32_t short_count;         // rows appended for this Seq2 (beyond kShortRowsPerSeq: given up)
 };
+
+// Shortlist of the enumeration stage.  The candidate the reference reports has a fixed-point score
+// within SeqDesc::enum_slack of the enumerated maximum (twice the rigorous bound between the
+// fixed-point and the float32 left-to-right sum), so every (offset, p) that has such a candidate is
+// listed as a row, with the 256-wide blocks of q that hold one, and the listed blocks are replayed
+// in float32 exactly as P/cudaFunctions.cu:210-220 adds them.  One list per run for the whole
+// batch; a Seq2 with more than kShortRowsPerSeq rows is given up (a low-entropy input can put
+// every row inside the window), whatever else the batch holds.
+struct ShortRow {
+  int32_t seq;
+  int32_t s;
+  uint32_t p;
+  uint32_t qmask;           // bit c: some q in [256 c, 256 c + 256) lies inside the window
+  unsigned long long best;  // replay: max over the row's q of (score image << 32 | ~q)
+};
+constexpr int kShortRowsPerSeq = 1024;
+// What the record kernel reports of a Seq2's shortlist (pinned host memory, beside the records).
+struct ShortOut {
+  uint32_t score_bits;  // the replayed winner: highest float32 score, ties to the smallest (n, k, offset)
+  int32_t n, k, offset;
+  int32_t counts[4];
+  int32_t count;        // rows replayed
+  int32_t state;        // 0: no shortlist in this run, 1: complete, 2: given up (the winner fields are void)
+};
+constexpr int kShortPList = 256;  // most positions p of one offset that may reach the window
 
 // ns consecutive offsets of one Seq2: the unit of the enumeration pre-pass, which writes
 // the g values of those offsets (and of the offset after them: f of an offset is read from the

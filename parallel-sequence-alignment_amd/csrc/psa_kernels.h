@@ -25,6 +25,9 @@ struct EnumParams {
   const float *table_t;            // float table [seq2 code][seq1 code], stride 32, 27 rows
   unsigned long long *chunk_best;  // per chunk: max of its waves' (maximum, smallest p) keys
   int *fg;                         // slab the pre-pass writes: per offset 64*nruns f values, then 64*nruns g values
+  ShortRow *short_rows;            // locate: this run's shortlist (null: none), ...
+  unsigned *short_total;           // ... rows appended so far ...
+  int short_rows_cap;              // ... and the list's capacity
 };
 
 // psa_enum_wave: one unit of work per (chunk, sub-run of its offsets, level).  Level w owns the
@@ -56,6 +59,11 @@ struct ResolveParams {
   ActiveOffset *active;  // offsets whose maximum equals their Seq2's maximum
   unsigned *nactive;
   int pchunks;           // ceil(max len2 / 256)
+  // replay of the enumeration stage's shortlist (launch_short_replay only)
+  ShortRow *short_rows;
+  const unsigned *short_total;
+  int short_rows_cap;
+  SeqAcc *eacc;          // the run's copy of the enumeration accumulators
 };
 
 struct FinalParams {
@@ -69,6 +77,8 @@ struct FinalParams {
   psa_result *out;               // pinned host memory, written directly
   uint32_t stages;  // stages of the run
   uint32_t which;   // PSA_STAGE_* bits: the halves of the records this launch fills
+  unsigned *short_total;  // this run's shortlist row counter (null: no shortlist): reset by the enumeration half ...
+  ShortOut *short_out;    // ... which reports the replayed winners here (pinned host memory)
 };
 
 int enum_class_of(int len2);          // -1 if len2 is too long
@@ -95,6 +105,9 @@ hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t 
 hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, bool use_mfma, int waves_per_group, int lds_bytes,
                             hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st);
+// float32 replay of the shortlist rows that locate appended (P.short_rows, P.short_total, P.eacc), then the
+// smallest offset among the rows that attain each Seq2's best
+hipError_t launch_short_replay(const ResolveParams &P, int max_len2, int grid, hipStream_t st);
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,
                           hipEvent_t ev_start);
 hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) void psa_na_setup(NaSetup P) {
     d.s_end = P.s_end;
     d.frac_bits = -1;
     d.enum_ns = 1;
+    d.enum_slack = -1;
+    d.pad_ = 0;
     *(SeqDesc *)(P.base + kOffDesc) = d;
     SeqAcc a;
     a.enum_key = 0ull;
@@ -121,6 +123,9 @@ __global__ __launch_bounds__(256) void psa_na_setup(NaSetup P) {
     a.res_loc = ~0ull;
     a.res_key = 0u;
     a.res_p = INT_MAX;
+    a.short_best = 0ull;
+    a.short_s = ~0u;
+    a.short_count = 0u;
     SeqAcc *acc = (SeqAcc *)(P.base + kOffAcc);
     acc[0] = a;
     acc[1] = a;

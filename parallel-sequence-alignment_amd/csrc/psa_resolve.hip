@@ -40,6 +40,9 @@ __global__ void psa_init_acc(SeqAcc *acc, int n, unsigned *counters, int ncounte
     a.res_loc = ~0ull;
     a.res_key = 0u;
     a.res_p = INT_MAX;
+    a.short_best = 0ull;
+    a.short_s = ~0u;
+    a.short_count = 0u;
     acc[i] = a;
   }
   if (i < ncounters) counters[i] = 0u;
@@ -483,7 +486,13 @@ __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
 // pass 4: with p* fixed, lane q evaluates score(s,p*,q) exactly as the reference adds
 // it: the one-deletion chain value before position q, then d2[j] for j > q (skewed in
 // time like pass 3).  The smallest q, then the smallest offset, wins.
-__global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
+//
+// ROWS: the same evaluation for the rows of the enumeration stage's shortlist instead of the
+// offsets that attain the float32 maximum -- p comes from the row, only the blocks of q the row
+// names are visited, and the row keeps max_q of (score image, ~q): the highest score of its
+// candidates and the smallest q that attains it; the Seq2 keeps the max of (score image, ~p, ~q).
+template <bool ROWS>
+__device__ __forceinline__ void first_q_body(const ResolveParams &P) {
   extern __shared__ __align__(16) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);  // short dependent chains: win VALU arbitration against the enumeration waves
   PSA_TS_DECL()
@@ -492,26 +501,42 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
   float *T = (float *)smem;
   const int tid = threadIdx.x;
   for (int i = tid; i < kDevTable; i += 256) T[i] = P.table_t[i];
-  const unsigned nact = *P.nactive;
+  const unsigned nact = ROWS ? min(*P.short_total, (unsigned)P.short_rows_cap) : *P.nactive;
   const long long nitems = (long long)nact * P.pchunks;
   PSA_TS()
   for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
     ActiveOffset ao;
-    ao.seq = uni(P.active[item / P.pchunks].seq);
-    ao.s = uni(P.active[item / P.pchunks].s);
     const int qc = (int)(item % P.pchunks);
-    // (requested together with the descriptor: one memory round trip, not three)
-    const unsigned long long known = tid == 0 ? P.acc[ao.seq].res_loc : ~0ull;
-    const float fstar = key2f(P.acc[ao.seq].res_key);
-    const int pstar = uni(P.acc[ao.seq].res_p);
+    unsigned long long known = ~0ull;
+    float fstar = 0.0f;
+    int pstar;
+    ShortRow *row = nullptr;
+    if (ROWS) {
+      // (everything read here is final: the kernel that lists the rows has finished)
+      row = P.short_rows + item / P.pchunks;
+      if (!uni((int)((row->qmask >> qc) & 1u))) continue;
+      ao.seq = uni(row->seq);
+      ao.s = uni(row->s);
+      pstar = uni((int)row->p);
+      if (uni((int)(P.eacc[ao.seq].short_count > (unsigned)kShortRowsPerSeq))) continue;  // given up
+    } else {
+      ao.seq = uni(P.active[item / P.pchunks].seq);
+      ao.s = uni(P.active[item / P.pchunks].s);
+      // (requested together with the descriptor: one memory round trip, not three)
+      known = tid == 0 ? P.acc[ao.seq].res_loc : ~0ull;
+      fstar = key2f(P.acc[ao.seq].res_key);
+      pstar = uni(P.acc[ao.seq].res_p);
+    }
     const SeqDesc d = load_desc(P.desc + ao.seq);
     const int L2 = d.len2;
     const int q0 = qc * 256;
     if (pstar == INT_MAX || q0 > L2 - 1 || q0 + 255 <= pstar) continue;
     __syncthreads();
-    if (tid == 0) skip_flag[0] = known != ~0ull && (int)(known >> 32) < q0;  // a smaller q is already known
-    __syncthreads();
-    if (uni(skip_flag[0])) continue;  // one decision for the whole block
+    if (!ROWS) {
+      if (tid == 0) skip_flag[0] = known != ~0ull && (int)(known >> 32) < q0;  // a smaller q is already known
+      __syncthreads();
+      if (uni(skip_flag[0])) continue;  // one decision for the whole block
+    }
     float *d0 = T + kDevTable;
     f2 *d21 = (f2 *)(d0 + tie_d0_len(L2));
     PSA_TS()
@@ -563,10 +588,22 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
 #undef PSA_LOAD
 #undef PSA_ADDS
     PSA_TS()
-    unsigned long long cand = ~0ull;
-    if (q > pstar && q <= L2 - 1 && c == fstar) cand = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)ao.s;
-    cand = wave_min_u64(cand);
-    if ((tid & 63) == 0 && cand != ~0ull) atomicMin(&P.acc[ao.seq].res_loc, cand);
+    if (ROWS) {
+      unsigned long long k = 0ull;
+      if (q > pstar && q <= L2 - 1) k = ((unsigned long long)f2key(c) << 32) | (0xffffffffu - (uint32_t)q);
+      k = wave_max_u64(k);
+      if ((tid & 63) == 0 && k != 0ull) {
+        atomicMax(&row->best, k);
+        const unsigned long long qmin = 0xffffffffu - (uint32_t)k;
+        atomicMax(&P.eacc[ao.seq].short_best, (k & 0xffffffff00000000ull) | ((unsigned long long)(0xffffu - (uint32_t)pstar) << 16) |
+                                                  (0xffffull - qmin));
+      }
+    } else {
+      unsigned long long cand = ~0ull;
+      if (q > pstar && q <= L2 - 1 && c == fstar) cand = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)ao.s;
+      cand = wave_min_u64(cand);
+      if ((tid & 63) == 0 && cand != ~0ull) atomicMin(&P.acc[ao.seq].res_loc, cand);
+    }
 #ifdef PSA_TRACE
     PSA_TS()
     if (tid == 0 && blockIdx.x < 8)
@@ -574,6 +611,22 @@ __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) {
              pstar, L2, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4], ts_[6] - ts_[5], ts_[7] - ts_[6]);
     nts_ = 2;
 #endif
+  }
+}
+
+__global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) { first_q_body<false>(P); }
+__global__ __launch_bounds__(256) void psa_short_rows(ResolveParams P) { first_q_body<true>(P); }
+
+// The smallest offset among the rows whose best candidate is their Seq2's best (score, p, q).
+__global__ __launch_bounds__(256) void psa_short_pick(ResolveParams P) {
+  const unsigned n = min(*P.short_total, (unsigned)P.short_rows_cap);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const ShortRow r = P.short_rows[i];
+    if (r.best == 0ull) continue;
+    const unsigned long long qmin = 0xffffffffu - (uint32_t)r.best;
+    const unsigned long long k = (r.best & 0xffffffff00000000ull) | ((unsigned long long)(0xffffu - r.p) << 16) | (0xffffull - qmin);
+    SeqAcc *a = P.eacc + r.seq;
+    if (a->short_count <= (unsigned)kShortRowsPerSeq && k == a->short_best) atomicMin(&a->short_s, (uint32_t)r.s);
   }
 }
 
@@ -646,6 +699,10 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
     if (P.which & P.stages & PSA_STAGE_ENUMERATE) {
       P.eacc[i].enum_key = 0ull;
       P.eacc[i].enum_loc = ~0ull;
+      P.eacc[i].short_best = 0ull;
+      P.eacc[i].short_s = ~0u;
+      P.eacc[i].short_count = 0u;
+      if (i == 0 && P.short_total) *P.short_total = 0u;  // (its readers ran before this kernel on the same stream)
     }
   }
   if (uni((int)(P.which & PSA_STAGE_RESOLVE))) {
@@ -686,6 +743,34 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
       r->enum_n = r->enum_k = r->enum_offset = r->enum_score = 0;
       r->enum_counts[0] = r->enum_counts[1] = r->enum_counts[2] = r->enum_counts[3] = 0;
     }
+    // The replayed shortlist of this Seq2: its winner is the highest float32 score, ties to the
+    // smallest (n, k, offset) -- the order in which the reference keeps the first maximum
+    // (S/main.c:44-83: mutants outer, offsets inner, strict >).
+    if (P.short_out) {
+      ShortOut *so = P.short_out + i;
+      const bool listed = uni(enum_ok && P.short_total && d.enum_slack >= 0);
+      const bool complete = uni(listed && ea.short_count <= (unsigned)kShortRowsPerSeq && ea.short_best != 0ull && ea.short_s != ~0u);
+      if (complete) {
+        const int p = (int)(0xffffu - (uint32_t)((ea.short_best >> 16) & 0xffffu));
+        const int q = (int)(0xffffu - (uint32_t)(ea.short_best & 0xffffu));
+        const int s = (int)ea.short_s;
+        count_classes(P, d, s, p, q, lds_class, lds_counts, so->counts);
+        if (tid == 0) {
+          so->score_bits = __float_as_uint(key2f((uint32_t)(ea.short_best >> 32)));
+          so->n = p + 1;
+          so->k = q + 1;
+          so->offset = s;
+          so->count = (int)ea.short_count;
+          so->state = 1;
+        }
+      } else if (tid == 0) {
+        so->score_bits = 0u;
+        so->n = so->k = so->offset = 0;
+        so->counts[0] = so->counts[1] = so->counts[2] = so->counts[3] = 0;
+        so->count = listed ? (int)min(ea.short_count, (unsigned)kShortRowsPerSeq) : 0;
+        so->state = listed ? 2 : 0;
+      }
+    }
   }
 }
 
@@ -719,6 +804,9 @@ __global__ __launch_bounds__(256) void psa_setup_small(const uint4 *src, uint4 *
     a.res_loc = ~0ull;
     a.res_key = 0u;
     a.res_p = INT_MAX;
+    a.short_best = 0ull;
+    a.short_s = ~0u;
+    a.short_count = 0u;
     acc[i] = a;
   }
   if (i < ncounters) counters[i] = 0u;
@@ -758,6 +846,8 @@ hipError_t set_resolve_kernel_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)psa_first_q, hipFuncAttributeMaxDynamicSharedMemorySize, tb);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)psa_short_rows, hipFuncAttributeMaxDynamicSharedMemorySize, tb);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void *)psa_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)fwd_lds(PSA_MAX_SEQ2));
 }
@@ -778,6 +868,17 @@ hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2,
   hipLaunchKernelGGL(psa_first_q, dim3(tie_grid), dim3(256), tb, st, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_first_q");
+}
+
+hipError_t launch_short_replay(const ResolveParams &P, int max_len2, int grid, hipStream_t st) {
+  if (!P.short_rows) return hipSuccess;
+  hipLaunchKernelGGL(psa_short_rows, dim3(grid), dim3(256), tie_lds(max_len2), st, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if ((e = debug_sync("psa_short_rows")) != hipSuccess) return e;
+  hipLaunchKernelGGL(psa_short_pick, dim3(std::max(1, std::min(1024, P.short_rows_cap / 256))), dim3(256), 0, st, P);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return debug_sync("psa_short_pick");
 }
 
 hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {

@@ -89,6 +89,7 @@ def lib():
     L.psa_batch_wait.argtypes = [vp]
     L.psa_batch_results.argtypes = [vp, C.POINTER(Result)]
     L.psa_batch_timing.argtypes = [vp, f32p, f32p]
+    L.psa_batch_shortlist.argtypes = [vp, i32p, i32p]
     L.psa_batch_size.argtypes = [vp]
     L.psa_batch_destroy.argtypes = [vp]
     L.psa_batch_destroy.restype = None
@@ -375,6 +376,13 @@ class Batch:
         _check(lib().psa_batch_run_allgather(self._h, nranks, _allgather_callback(allgather, nranks), None, stages,
                                              C.byref(out)), "psa_batch_run_allgather")
         return out
+
+    def shortlist(self):
+        """Per Seq2 of the last run: (entries of its shortlist, state) -- state 0 no shortlist, 1 complete and
+        replayed in float32, 2 overflowed."""
+        cnt, st = (C.c_int32 * max(self.n, 1))(), (C.c_int32 * max(self.n, 1))()
+        _check(lib().psa_batch_shortlist(self._h, cnt, st), "psa_batch_shortlist")
+        return list(zip(cnt, st))[:self.n]
 
     def timing(self):
         """(enumeration kernel ms, first launch to last completion ms) of the last run"""

@@ -56,7 +56,8 @@ def check_against_oracle(oracle, seq1, seq2s, table, results, expect=None, enum=
                 m, u = L2 - 2, 2.0 ** -24
                 b = (m - 1) * u / (1 - (m - 1) * u) * m * float(np.abs(table).max()) + m * 2.0 ** -(fr + 1)
                 assert abs(float(r.score) - r.enum_score * 2.0 ** -fr) <= b, ("maxima apart", i, r.score, r.enum_score, fr, b)
-                assert r.enum_check == 1, ("the library's own cross-check", i, r.enum_check)
+                # 2: the float32 replay of the shortlisted candidates gave this very record; 1: the list overflowed
+                assert r.enum_check in (1, 2), ("the library's own cross-check", i, r.enum_check)
                 ef = oracle.enum_score(seq1, seq2, itab, r.offset, r.n, r.k)
                 assert ef <= r.enum_score and (r.enum_score - ef) * 2.0 ** -fr <= 2 * b, ("winner apart", i, ef, r.enum_score)
 
@@ -248,9 +249,96 @@ def test_runs_back_to_back_alternate(psa, oracle, monkeypatch):
         b.enqueue(psa.STAGE_ENUMERATE)
         b.wait()
         assert [r.enum_key() + tuple(r.enum_counts) for r in b.results()] == [w[4:8] + w[12:16] for w in want]
-        assert all(r.n == 0 and r.score_bits == 0 for r in b.results())
+        # the float32 half of an enumeration-only run comes from the replayed shortlist, or stays empty
+        for r, (cnt, state), w_ in zip(b.results(), b.shortlist(), want):
+            assert (state == 1 and cnt >= 1 and r.key() + tuple(r.counts) == w_[:4] + w_[8:12]) or \
+                   (state == 2 and r.n == 0 and r.score_bits == 0), (state, cnt, r.key())
         b.close()
         c.close()
+
+
+def test_shortlist_replay(psa, oracle, golden, monkeypatch):
+    """The enumeration stage's shortlist: every candidate within the rounding window of the enumerated
+    maximum, replayed in float32.  On inputs with few near-maximal candidates the replayed winner is the
+    reference's record (enum_check = 2) and an enumeration-only run returns it; a list that overflows
+    is given up (enum_check = 1, enumeration-only run without a float32 record)."""
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    seq1, seq2s = synth_problem(31, 3000, [2000, 1999, 700, 301, 64, 5, 2])
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    b = c.batch(seq2s)
+    both = b.run()
+    check_against_oracle(oracle, seq1, seq2s, table, both)
+    sl = b.shortlist()
+    # (the Seq2 of two characters has one mutant, the empty one, which scores 0 at every offset: 3001 ties)
+    assert all(r.enum_check == 2 for r in both[:-1]) and both[-1].enum_check == 1, [r.enum_check for r in both]
+    assert all(state == 1 and cnt >= 1 for cnt, state in sl[:-1]) and sl[-1][1] == 2, sl
+    only = b.run(psa.STAGE_ENUMERATE)
+    for r, r2 in zip(only[:-1], both):
+        assert r.key() == r2.key() and tuple(r.counts) == tuple(r2.counts) and r.mutant_num == r2.mutant_num
+        assert r.enum_key() == r2.enum_key() and r.enum_check == 0
+    assert only[-1].n == 0 and only[-1].enum_key() == both[-1].enum_key()
+    assert b.shortlist() == sl
+    res_only = b.run(psa.STAGE_RESOLVE)
+    assert [r.key() for r in res_only] == [r.key() for r in both]
+    assert all(state == 0 for _, state in b.shortlist())
+    b.close()
+    # the reference's own sample input
+    case = golden[0]
+    c.set_seq1(case["seq1"])
+    c.set_weights(parse_weights(case["weights"]))
+    res = c.score_batch(case["seq2"])
+    check_against_oracle(oracle, case["seq1"], case["seq2"], oracle.comp_matrix(parse_weights(case["weights"])), res,
+                         expect=case["expected"])
+    assert all(r.enum_check == 2 for r in res), [r.enum_check for r in res]
+    # every row inside the window (all-same sequences): more rows than a Seq2's quota, the list is given up
+    rng = np.random.default_rng(5)
+    seq1 = "AB" * 200
+    seq2s = ["AB" * 45, "A" * 200, synth_seq(rng, 120, "ACDEFGHIKLMNPQRSTVWY")]
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    b = c.batch(seq2s)
+    res = b.run()
+    check_against_oracle(oracle, seq1, seq2s, table, res)
+    sl = b.shortlist()
+    assert sl[1][1] == 2 and res[1].enum_check == 1, (sl, [r.enum_check for r in res])
+    only = b.run(psa.STAGE_ENUMERATE)
+    for r, o, (cnt, state) in zip(res, only, sl):
+        assert o.enum_key() == r.enum_key()
+        if state == 1:
+            assert r.enum_check == 2 and o.key() == r.key()
+        else:
+            assert state == 2 and r.enum_check == 1 and o.n == 0 and o.score_bits == 0
+    b.close()
+    # a run's list that is full (capacity forced down to 3 rows): the Seq2 that find it full are given up
+    monkeypatch.setenv("PSA_SHORT_ROWS", "3")
+    seq1b, seq2b = synth_problem(32, 1200, [300, 280, 250, 200])
+    c.set_seq1(seq1b)
+    b = c.batch(seq2b)
+    monkeypatch.delenv("PSA_SHORT_ROWS")
+    res = b.run()
+    check_against_oracle(oracle, seq1b, seq2b, table, res)
+    sl = b.shortlist()
+    assert any(state == 2 for _, state in sl) and all((r.enum_check == 2) == (state == 1) for r, (_, state) in zip(res, sl)), sl
+    again = b.run()  # the counters were left reset
+    assert [bytes(r) for r in again] == [bytes(r) for r in res] or b.shortlist() != sl  # (which Seq2 find the list full is a race)
+    check_against_oracle(oracle, seq1b, seq2b, table, again)
+    b.close()
+    c.close()
+    # switched off
+    monkeypatch.setenv("PSA_SHORTLIST", "0")
+    c = psa.Context(0)
+    monkeypatch.delenv("PSA_SHORTLIST")
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    b = c.batch(seq2s)
+    res = b.run()
+    check_against_oracle(oracle, seq1, seq2s, table, res)
+    assert all(r.enum_check == 1 for r in res) and all(state == 0 for _, state in b.shortlist())
+    b.close()
+    c.close()
 
 
 def test_edge_stress(psa, ctx, oracle):
