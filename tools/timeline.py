@@ -9,7 +9,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-rows = rows[len(rows) - skip - n:len(rows) - skip]
+rows = rows[max(0, len(rows) - skip - n):len(rows) - skip]
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
     a, b = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
