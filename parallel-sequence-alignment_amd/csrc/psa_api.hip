@@ -915,6 +915,11 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       PSA_HIP(psa::launch_short_replay(R, b->max_len2, std::max(256, std::min(4096, b->nvalid * R.pchunks * 8)), st_tail));
     }
     F.which = resolve ? PSA_STAGE_ENUMERATE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
+    // Record kernels of runs without the resolve stage clear the float32 half of the records.  Two
+    // such runs in a row end on different streams; the next resolve chain waits for the later one
+    // only (enum_only_tail), so the earlier one's record kernel must not be able to land behind it:
+    // the tails of consecutive runs without the resolve stage form a chain.
+    if (!resolve && b->enum_only_tail) PSA_HIP(hipStreamWaitEvent(st_tail, b->enum_only_tail, 0));
     b->ev_last = b->ev_tail[par];
     PSA_HIP(psa::launch_finalize(F, b->n, st_tail, nullptr, b->ev_last));
     PSA_HIP(psa::debug_sync("psa_finalize"));

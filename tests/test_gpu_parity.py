@@ -239,6 +239,15 @@ def test_runs_back_to_back_alternate(psa, oracle, monkeypatch):
         b.enqueue()
         b.wait()
         assert [r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in b.results()] == want
+        # two runs without the resolve stage in a row end on different streams, and each one's record
+        # kernel clears the float32 half: neither may land behind the record kernels of the run after them
+        for _ in range(6):
+            b.enqueue()
+            b.enqueue(psa.STAGE_ENUMERATE)
+            b.enqueue(psa.STAGE_ENUMERATE)
+            b.enqueue()
+            b.wait()
+            assert [r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) for r in b.results()] == want
         # mixed stages back to back: the records are those of the last run enqueued
         b.enqueue()
         b.enqueue(psa.STAGE_RESOLVE)

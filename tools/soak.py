@@ -36,9 +36,12 @@ while time.time() - t0 < secs:
         hist[i].append('w')
         got, st = full(batches[i]), last[i]
         last[i] = None
-        for g, w in zip(got, want[i]):
+        short = batches[i].shortlist()
+        for g, w, (_, sstate) in zip(got, want[i], short):
             exp = list(w)
-            if not st & psa_amd.STAGE_RESOLVE:
+            # a run of the enumeration stage alone reports the float32 answer from its replayed
+            # shortlist when that list is complete, and leaves the float32 half empty otherwise
+            if not st & psa_amd.STAGE_RESOLVE and not (st & psa_amd.STAGE_ENUMERATE and sstate == 1):
                 exp[0:4] = [0, 0, 0, 0]; exp[8:12] = [0, 0, 0, 0]
             if not st & psa_amd.STAGE_ENUMERATE:
                 exp[4:8] = [0, 0, 0, 0]; exp[12:16] = [0, 0, 0, 0]
