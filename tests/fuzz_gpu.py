@@ -24,6 +24,7 @@ oracle.build()
 ctx = psa_amd.Context(0)
 WEIGHTS = ([2, 1.5, 1.1, 1.3], [1, 1, 1, 1], [3, 0.7, 0.2, 5], [1.1, 1.1, 1.3, 1.3], [2, 1.5, 1, 1.25], [0, 0, 0, 1])
 t0, cases, seqs = time.time(), 0, 0
+alone_ok = alone_over = 0
 while time.time() - t0 < secs:
     kind = rng.random()
     if kind < 0.08:
@@ -74,10 +75,28 @@ while time.time() - t0 < secs:
         ctx.set_weights(w)
     try:
         check_against_oracle(oracle, seq1, seq2s, table, ctx.score_batch(seq2s))
+        if rng.random() < 0.25:
+            # the enumeration stage alone: where its shortlist is complete, the replayed winner is the
+            # reference's answer; where it overflowed, the float32 half stays empty
+            b = ctx.batch(seq2s)
+            b.run(psa_amd.STAGE_ENUMERATE)
+            for s2, r, (cnt, state) in zip(seq2s, b.results(), b.shortlist()):
+                if r.enum_frac_bits < 0:
+                    continue
+                if state == 1:
+                    o = oracle.fast(seq1, s2, table)
+                    assert r.key() == o.as_tuple(), ("enumeration alone", s2[:40], r.key(), o.as_tuple())
+                    assert tuple(r.counts) == oracle.counts(seq1, s2, r.offset, r.n, r.k)
+                    alone_ok += 1
+                else:
+                    assert state == 2 and r.n == 0 and r.score_bits == 0, (state, r.key())
+                    alone_over += 1
+            b.close()
     except AssertionError:
         print("MISMATCH seed=%d case=%d L1=%d lens=%r alpha=%r" % (seed, cases, L1, lens, alpha))
         raise
     cases += 1
     seqs += len(seq2s)
 ctx.close()
-print("fuzz ok: %d batches, %d Seq2 in %.1f s (seed %d)" % (cases, seqs, time.time() - t0, seed))
+print("fuzz ok: %d batches, %d Seq2 in %.1f s (seed %d); enumeration stage alone: %d answers from the shortlist, %d lists overflowed"
+      % (cases, seqs, time.time() - t0, seed, alone_ok, alone_over))
