@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box from the repository root: round-2 bench lines, rocprofv3 kernel statistics and
+# Run on the GPU box from the repository root: bench lines, rocprofv3 kernel statistics and
 # PMC passes into gpurun_out/prof/ (copy what is to be kept into profiles/).  A step that fails ends the script.
 set -o pipefail
 tag=r02
