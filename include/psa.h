@@ -85,13 +85,14 @@ typedef struct psa_result {
  * reference, which scores once.
  *
  * The shortlist.  The candidate the reference reports has a fixed-point score within 2b of the enumerated
- * maximum, so an enumerating run collects every candidate inside that window (per Seq2 up to a capacity of
- * 256 to 8192 entries, depending on the batch size) and replays each one in float32 exactly as
- * calcMutantScore adds it (P/cudaFunctions.cu:210-220); the replayed winner -- highest score, ties to the
- * smallest (n, k, offset) -- is then the reference's answer, obtained from the enumerated candidates alone.
+ * maximum, so an enumerating run lists every row (offset, n) that holds a candidate inside that window, with
+ * the 256-wide blocks of k that hold one (per Seq2 up to 1024 rows and 256 listed n per offset, per run up
+ * to 2^20 rows), and replays the listed blocks in float32 exactly as calcMutantScore adds a candidate
+ * (P/cudaFunctions.cu:210-220); the replayed winner -- highest score, ties to the smallest (n, k, offset) --
+ * is then the reference's answer, obtained from the enumerated candidates alone.
  *   - Run with both stages: enum_check = 2 when that winner equals the resolve stage's record bit for bit
  *     (score bits, n, k, offset), -2 when it does not (a defect), and stays 1 when the list overflowed
- *     (low-entropy inputs can put millions of candidates inside the window) -- the bound above still holds.
+ *     (low-entropy inputs can put every row inside the window) -- the bound above still holds.
  *   - Run with PSA_STAGE_ENUMERATE alone: n, k, offset, mutant_num, score, score_bits and counts are filled
  *     from the replayed winner when the list is complete, and stay 0 when it overflowed (run the resolve
  *     stage then); psa_batch_shortlist tells which.
@@ -161,7 +162,7 @@ int psa_batch_results(const psa_batch *b, psa_result *out);
  * the time during which a candidate-loop kernel of the enumeration stage was executing (passes of a
  * large batch overlap), and first kernel start to last kernel end */
 int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms);
-/* per Seq2 of the last run: entries of its shortlist (see enum_check) and the list's state -- 0 no shortlist
+/* per Seq2 of the last run: rows of its shortlist (see enum_check) and the list's state -- 0 no shortlist
  * (stage not run, switched off, invalid Seq2), 1 complete and replayed, 2 overflowed.  Either array may be
  * NULL.  No counterpart in the reference. */
 int psa_batch_shortlist(const psa_batch *b, int32_t *count, int32_t *state);
