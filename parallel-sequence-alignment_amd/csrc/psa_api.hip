@@ -30,7 +30,7 @@ thread_local std::string g_err;
 
 constexpr size_t kSlabUnit = 256;                 // bytes: one run of 64 int32
 constexpr size_t kSlabMinUnits = (5u << 20) / 256;  // the largest chunk (64 + 1 rows of 128 + 1 runs) fits
-constexpr size_t kSlabDefaultMiB = 512;  // against 2048: one long pair 1.6 % faster, a large mixed batch 1 % slower, a quarter of the memory
+constexpr size_t kSlabDefaultMiB = 256;  // against 512: one long pair 1.8 % faster, a list of 4096 Seq2 0.4 %, half the memory (2048: 3.4 % slower on the pair)
 
 // Device block, pinned host block and events of one batch.  A context keeps the bundles of
 // destroyed batches and hands them to new ones, so that scoring batch after batch through
