@@ -510,8 +510,11 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     d.enum_ns = (int32_t)std::max<int64_t>(1, std::min<int64_t>(ns, psa::kEnumMaxNs));
     min_ns = std::min(min_ns, d.enum_ns);
   }
-  // chunks of at least 8 offsets: a chunk's pre-pass scans two diagonals and stores one row more than it has offsets
-  int sub_log2 = min_ns >= 8 ? 0 : (min_ns >= 4 ? 1 : (min_ns >= 2 ? 2 : 3));
+  // chunks of at least 4 offsets: a chunk's pre-pass scans two diagonals and stores one row more than it has
+  // offsets, but locate walks a chunk it visits offset by offset, and on a small batch it sits between one
+  // candidate loop and the next but one (chunks of at least 8: one-shot calls 5 % slower on 4 x Seq2 = 2000,
+  // steps with a host wait 16 % slower on the reference's input.txt)
+  int sub_log2 = min_ns >= 4 ? 0 : (min_ns >= 2 ? 1 : 2);
   if (const char *e = std::getenv("PSA_ENUM_SUB_LOG2")) sub_log2 = std::max(0, std::min(3, std::atoi(e)));  // tuning aid
   size_t total_units = 0;
   for (int i : order) {
