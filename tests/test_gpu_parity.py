@@ -775,6 +775,8 @@ def test_stream_of_batches(psa, oracle):
 def test_clock_probe_variant(psa, oracle):
     """The stamped variant of the candidate loop returns the same records as the plain one, and the
     clock it reports is a shader clock this chip can hold."""
+    if os.environ.get("PSA_ENUM_MFMA") == "0" or os.environ.get("PSA_ENUM_I32") == "1":
+        pytest.skip("the probe exists in the matrix-core candidate loop only")
     seq1, seq2s = synth_problem(94, 3000, [2000, 700, 1300, 64])
     w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
     c = psa.Context(0)
