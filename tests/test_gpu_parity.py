@@ -2,6 +2,8 @@
 vectors the compiled reference produced.  Bit-exact bar: n, k, offset and the
 float32 score bits; class counts; and for the enumeration stage the fixed-point
 score and its first maximiser."""
+import os
+
 import numpy as np
 import pytest
 
