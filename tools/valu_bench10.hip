@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     b4[i] = b[i];
   }
   frag_cd d0 = {}, d1 = {};
+  frag_cd mk;  // a tile that is not all zeros and stays in registers
+  for (int i = 0; i < 16; ++i) mk[i] = (float)((threadIdx.x + i) & 3);
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
     if (MODE <= 3) {
@@ -87,6 +89,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     } else if (MODE == 7) {
       d0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, d0, 0, 0, 0);
       d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, d1, 0, 0, 0);
+    } else if (MODE == 9) {
+      // as 8, the matrix instruction on top of a tile held in registers (the mask of a diagonal tile)
+      d0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, mk, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) MAX3(acc[i], __float_as_int(d1[2 * i]), __float_as_int(d1[2 * i + 1]));
+      d1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(b4, a4, mk, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) MAX3(acc[i], __float_as_int(d0[2 * i]), __float_as_int(d0[2 * i + 1]));
     } else if (MODE == 8) {
       const frag_cd z = {};
       d0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, z, 0, 0, 0);
@@ -199,5 +207,6 @@ int main() {
   run<6>("6: v_mfma_f32_32x32x16_bf16 alone", d_out, d_g, d_st, 2048);
   run<7>("7: v_mfma_f32_32x32x8_bf16_1k alone (two-register operands)", d_out, d_g, d_st, 2048);
   run<8>("8: v_mfma_f32_32x32x8_bf16_1k + 8 v_max3_f32 per 1024 candidates", d_out, d_g, d_st, 2048);
+  run<9>("9: as 8 with the C operand in registers (diagonal tiles)", d_out, d_g, d_st, 2048);
   return 0;
 }
