@@ -20,7 +20,10 @@ Workloads (BASELINE.json configs):
       among the ranks by psa_partition as the reference divides its list between its two ranks
       (P/main.c:62-76): strong scaling, no data-path collective, records gathered to rank 0
   c4  Seq1 = 200000, Seq2 = 8000, offsets sharded over the ranks; every step ends with the
-      all-gather of one record per rank and the max-loc combine, inside the timed region
+      all-gather of one record per rank (RCCL) and the max-loc combine, inside the timed region
+Process groups at N > 1: the default group is gloo and carries only control traffic outside the
+timed regions and off the data path (barriers, the broadcast of the c3 list, gathers of timings
+and records); the RCCL communicator is a second group, created when c4 first needs it.
 
 The default run (c2) also carries a `scale` block: c3 at full size and c4, a few steps each, on
 the same N ranks, so that runs at N = 1, 2, 4, 8 give strong-scaling curves for both
@@ -248,12 +251,17 @@ class Job:
         if self.world > 1 or args.force_dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
-            else:  # gloo: rehearsal of the N > 1 logic where the ranks cannot each have a GPU of their own
-                dist.init_process_group(args.backend)
+            # The default group is gloo in either case: barriers, the broadcast of the list and the gathers
+            # of timings and records are control plane, off the data path and outside the timed regions.
+            # With --backend nccl the RCCL communicator is a second group, created when the first workload
+            # with a data-path collective (the long pair's all-gather) needs it: a live RCCL communicator
+            # costs the other workloads' steps 7 % (one rank, C2: 0.166 ms per step without a process
+            # group, 0.170 with a gloo group, 0.182 with an RCCL one), and they never use it.
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the loopback interface
+            dist.init_process_group("gloo")
             self.dist = dist
         self.backend = args.backend
+        self._data_group = None
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -269,9 +277,18 @@ class Job:
         self.dist.all_gather_object(out, obj)
         return out
 
+    def data_group(self):
+        """The group of the data-path collective: RCCL (created on first use, by all ranks together) with
+        --backend nccl, the default gloo group in a rehearsal."""
+        if self.dist is None or self.backend != "nccl":
+            return None
+        if self._data_group is None:
+            self._data_group = self.dist.new_group(backend="nccl")
+        return self._data_group
+
     def allgather_bytes(self):
         from psa_amd import dist as pdist
-        return pdist.allgather_bytes() if self.dist is not None else None
+        return pdist.allgather_bytes(self.data_group()) if self.dist is not None else None
 
 
 def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_steps):
@@ -315,7 +332,7 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
     ctx.set_seq1(seq1)
     ctx.set_weights(WEIGHTS)
     batch = ctx.batch(my_seq2) if shard is None else ctx.batch_range(my_seq2[0], shard[0], shard[1])
-    gather_cb = job.allgather_bytes()
+    gather_cb = job.allgather_bytes() if shard is not None else None  # only the long pair exchanges anything
     combined = [None]
 
     def step_sync():
