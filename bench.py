@@ -283,7 +283,16 @@ class Job:
         if self.dist is None or self.backend != "nccl":
             return None
         if self._data_group is None:
-            self._data_group = self.dist.new_group(backend="nccl")
+            try:
+                g = self.dist.new_group(backend="nccl")
+                t = self.torch.zeros(1, device="cuda")
+                self.dist.all_reduce(t, group=g)  # builds the communicator here, not inside a timed step
+                self.torch.cuda.synchronize()
+                self._data_group = g
+            except Exception as e:  # no RCCL on this box: the rehearsal path, and the JSON says so
+                sys.stderr.write("bench.py: RCCL group not available (%s); the long pair's all-gather runs over gloo\n" % e)
+                self.backend = "gloo (RCCL group failed)"
+                return None
         return self._data_group
 
     def allgather_bytes(self):
@@ -652,6 +661,8 @@ def main():
             ws = run_workload(job, ctx, args, cfg, steps, 1, 0.0, 4096, False)
             scale[cfg] = scale_entry(ws, world)
             scale[cfg]["complaints"] = ws["complaints"][:5]
+        scale["c4"]["collective"] = ("rccl" if job._data_group is not None else
+                                     "gloo" if job.dist is not None else "none (one rank, no process group)")
         scale["note"] = ("c3 = BASELINE's list of 4096 Seq2 divided among the ranks by psa_partition (no data-path "
                          "collective, records gathered to rank 0 and compared with a one-rank run); c4 = one pair, "
                          "offsets sharded, one all-gather of a 96-byte record per rank and the max-loc combine "
