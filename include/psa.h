@@ -40,7 +40,9 @@ typedef enum psa_status {
                              context has batches, a batch used after its context was shut down, wait without enqueue */
   PSA_ERR_NOMEM = 8,
   PSA_ERR_COMM = 9,       /* the caller's all-gather callback reported a failure */
-  PSA_ERR_LIMIT = 10      /* beyond the fixed capacity of psa_score_range_noalloc */
+  PSA_ERR_LIMIT = 10,     /* beyond the fixed capacity of psa_score_range_noalloc */
+  PSA_ERR_CHECK = 11      /* psa_score_batch_answer with both stages: the two stages disagree on some Seq2
+                             (its record has enum_check < 0), i.e. a defect in one of them */
 } psa_status;
 
 /* stages of one run; 0 means both */
@@ -121,7 +123,9 @@ void psa_shutdown(psa_ctx *ctx);
 int psa_set_seq1(psa_ctx *ctx, const char *seq1, int64_t len1);
 /* table built from four weights exactly as createCompMatrix does (P/cFunctions.c:55-76) */
 int psa_set_weights(psa_ctx *ctx, const float weights[4]);
-/* any 26x26 float table, the argument calc_best_score_CUDA receives (P/myProto.h:20) */
+/* any 26x26 float table, the argument calc_best_score_CUDA receives (P/myProto.h:20).  Every entry
+ * must be finite: a NaN or an infinity returns PSA_ERR_ARG (the kernels' maxima are built on the
+ * premise that no NaN can arise; the reference's plain adds would carry one through to the score). */
 int psa_set_table(psa_ctx *ctx, const float table[PSA_TABLE_SIZE]);
 
 /* Measurement aid, no counterpart in the reference.  While enabled, the candidate loops of the
@@ -174,6 +178,23 @@ int psa_score_batch(psa_ctx *ctx, int n, const char *const *seq2, const int32_t 
                     psa_result *out);
 int psa_score_range(psa_ctx *ctx, const char *seq2, int32_t len2, int64_t s_begin, int64_t s_end,
                     uint32_t stages, psa_result *out);
+/* psa_score_batch for a host program that lets its user choose where the answer comes from -- the
+ * PSA_STAGES switch of the drop-in shim and of the host programs.  In the reference every call through
+ * the boundary runs the per-candidate kernel (P/cudaFunctions.cu:290-296, called at P/main.c:81, :130).
+ *   PSA_STAGE_RESOLVE                as psa_score_batch: the float32 recurrence alone;
+ *   PSA_STAGE_ENUMERATE | _RESOLVE   both stages; returns PSA_ERR_CHECK (records filled) if some record has
+ *                                    enum_check < 0;
+ *   PSA_STAGE_ENUMERATE              every candidate is scored by the candidate loop and the answer is the
+ *                                    float32 replay of the candidates near the enumerated maximum; the Seq2
+ *                                    whose list overflowed (low-entropy inputs) or whose table does not fit
+ *                                    the fixed-point range are then scored by the resolve stage, so that every
+ *                                    valid Seq2 gets the reference's answer either way.
+ * *fallbacks (may be NULL) receives the number of Seq2 that took that second path. */
+int psa_score_batch_answer(psa_ctx *ctx, int n, const char *const *seq2, const int32_t *len2, uint32_t stages,
+                           psa_result *out, int *fallbacks);
+/* "resolve", "enumerate", "both" (what PSA_STAGES and the host programs' --stages take) -> PSA_STAGE_* bits;
+ * NULL or "" -> PSA_STAGE_RESOLVE; anything else returns PSA_ERR_ARG */
+int psa_parse_stages(const char *text, uint32_t *stages);
 
 /* max-loc combine of the records that the shards of one long pair returned:
  * highest float32 score, ties to the smallest (n, k, offset); likewise for the
@@ -183,22 +204,34 @@ int psa_combine_results(const psa_result *parts, int nparts, psa_result *out);
 
 /* All-gather supplied by the caller: every rank contributes `bytes` bytes at `send` and receives
  * the contributions of all ranks, in rank order, at `recv` (nranks * bytes); both are host
- * memory.  Returns 0 on success.  One line around MPI_Allgather or ncclAllGather. */
+ * memory.  Returns 0 on success.  One line around MPI_Allgather or ncclAllGather.  `bytes` differs
+ * between the calls of one run (see below) and is the same on every rank in each of them. */
 typedef int (*psa_allgather_fn)(const void *send, void *recv, size_t bytes, void *comm);
-/* One long pair over nranks ranks, one GPU each, collective included: cuts the pair's offsets
- * [0, len1 - len2 + 3) into nranks contiguous shards, scores shard `rank` on this context's GPU,
- * exchanges one sizeof(psa_result)-byte record per rank through `allgather(.., comm)` and
- * combines them (psa_combine_results), so every rank returns the same record -- the answer
+#define PSA_EXCHANGE_MAX_BYTES 16  /* first exchange of an enumerating run: the shard's enumerated maximum */
+#define PSA_EXCHANGE_RECORD_BYTES 136 /* last exchange: the shard's record and its replayed shortlist winner */
+/* One long pair over nranks ranks, one GPU each, collectives included: cuts the pair's offsets
+ * [0, len1 - len2 + 3) into nranks contiguous shards, scores shard `rank` on this context's GPU and
+ * combines the shards' answers so that every rank returns the same record -- the answer
  * calc_best_score_CUDA would give for the whole pair (P/myProto.h:20; called per Seq2 at
- * P/main.c:81, :130).  Every rank of the communicator must call it; with nranks == 1 the
- * callback may be NULL.  A rank whose scoring fails still takes part in the all-gather and all
- * ranks return that status. */
+ * P/main.c:81, :130).  With nranks > 1 a run calls `allgather(.., comm)`
+ *   - once with PSA_EXCHANGE_MAX_BYTES per rank when the stages include the enumeration, after the
+ *     candidate loops: the shards' enumerated maxima, so that every shard shortlists against the GLOBAL
+ *     maximum (a shard far below it lists nothing) and the replayed candidates of all shards together
+ *     hold the reference's answer, as they do on one GPU;
+ *   - once with PSA_EXCHANGE_RECORD_BYTES per rank at the end: record and replayed winner of every shard,
+ *     combined by the max-loc rule of psa_combine_results; enum_check of the combined record is 2 when the
+ *     best replayed winner of all shards equals the combined float32 answer bit for bit (-2 if it does
+ *     not), 1 when some shard's list overflowed.
+ * Every rank of the communicator must call it, with the same stages; with nranks == 1 the callback may
+ * be NULL.  A rank whose scoring fails, or whose context is not ready, still takes part in every
+ * all-gather of the run and all ranks return that status.  A run of PSA_STAGE_ENUMERATE alone returns the
+ * float32 fields of the best replayed winner, or zeros if some shard's list overflowed. */
 int psa_score_range_allgather(psa_ctx *ctx, const char *seq2, int32_t len2, int rank, int nranks,
                               psa_allgather_fn allgather, void *comm, uint32_t stages, psa_result *out);
 /* The same on a resident batch: `shard` was made by psa_batch_create_range for this rank's offsets
- * (shard r of nranks owns [S*r/nranks, S*(r+1)/nranks), S = len1 - len2 + 3); one run, one
- * all-gather, the combine.  For callers that score the same pair repeatedly or keep their shard
- * in HBM. */
+ * (shard r of nranks owns [S*r/nranks, S*(r+1)/nranks), S = len1 - len2 + 3); one run, the all-gathers
+ * described above, the combine.  For callers that score the same pair repeatedly or keep their
+ * shard in HBM. */
 int psa_batch_run_allgather(psa_batch *shard, int nranks, psa_allgather_fn allgather, void *comm,
                             uint32_t stages, psa_result *out);
 

@@ -162,6 +162,11 @@ struct psa_batch {
   hipEvent_t ev_tail[2] = {nullptr, nullptr};  // copy i has been read and reset: end of that run's record kernel
   bool tail_recorded[2] = {false, false};
   int tail_stream[2] = {0, 0};                 // the candidate-loop stream that event is on
+  // a run enqueued in two parts (one shard of a long pair: the ranks exchange their enumerated maxima between
+  // the candidate loops and locate): what the first part leaves for the second
+  int head_es = 0;                                    // stream of the last candidate loop
+  hipEvent_t head_last_loop[2] = {nullptr, nullptr};  // end of the last candidate loop on each loop stream
+  bool global_ref = false;  // the pending run shortlisted against a maximum given from outside (see psa_batch_wait)
   bool last_run_res_only = false;  // the run before wrote both halves of the records on st_res
   bool res_recorded = false;       // ev_res has been recorded (some run had a record kernel on st_res)
   hipEvent_t enum_only_tail = nullptr;  // record kernel of a run without the resolve stage, not yet ordered before st_res
@@ -307,6 +312,11 @@ int psa_set_table(psa_ctx *c, const float table[PSA_TABLE_SIZE]) {
     g_err = "psa_set_table: the context still has batches (their fixed-point scale follows the current table)";
     return PSA_ERR_STATE;
   }
+  for (int i = 0; i < PSA_TABLE_SIZE; ++i)
+    if (!std::isfinite(table[i])) {
+      g_err = "psa_set_table: entry " + std::to_string(i) + " is not finite";
+      return PSA_ERR_ARG;
+    }
   std::memcpy(c->table, table, sizeof c->table);
   c->table_abs_max = 0.0;
   for (float x : c->table) c->table_abs_max = std::max(c->table_abs_max, (double)std::fabs(x));
@@ -768,12 +778,21 @@ int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
 // enumeration half of the records; the resolve chain with its half of the records on st_res.
 // No host synchronisation.  The events that time the run ride on kernel dispatches, the host
 // waits for the record kernels, and the accumulators are left reset by their last readers.
-static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
+// A run can be enqueued in two parts, with the host in between: kPartHead = set-up, pre-passes, candidate
+// loops, and the resolve chain with its half of the records; kPartTail = locate, the shortlist replay and
+// the enumeration half of the records.  One shard of a long pair runs that way: its rank waits for the
+// candidate loops, exchanges the enumerated maximum with the other ranks, and the second part shortlists
+// against the maximum over all shards (*short_ref).  A whole run is both parts at once, in the order
+// loops, locate and records, resolve chain.
+constexpr unsigned kPartHead = 1u, kPartTail = 2u;
+static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned parts = kPartHead | kPartTail,
+                       const int *short_ref = nullptr) {
   psa_ctx *c = b->ctx;
   const bool resolve = (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
   const bool enumerate = (stages & PSA_STAGE_ENUMERATE) && b->nchunks > 0;
+  const bool head = (parts & kPartHead) != 0, tail = (parts & kPartTail) != 0;
   // only a batch's first run, or one after a failed run, needs the set-up kernel
-  const bool init = !b->acc_ready;
+  const bool init = head && !b->acc_ready;
   if (init) {
     // on st_res, which never waits for a candidate loop
     if (b->setup_src) {
@@ -792,9 +811,9 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     for (hipStream_t st : c->st_enum) PSA_HIP(hipStreamWaitEvent(st, b->ev_init, 0));
     b->tail_recorded[0] = b->tail_recorded[1] = false;
   }
-  b->acc_ready = false;
+  if (head) b->acc_ready = false;
   *timed = false;
-  if (enumerate) b->acc_par ^= 1;
+  if (enumerate && head) b->acc_par ^= 1;
   const int par = b->acc_par;
   psa::SeqAcc *const eacc = b->d_acc + (size_t)par * (size_t)b->n;
   unsigned long long *const chunk_best = b->d_chunk_best + (size_t)par * (size_t)b->nchunks;
@@ -808,8 +827,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
   F.class_t = c->d_class_t;
   F.out = b->d_out;
   F.stages = stages;
+  psa::EnumParams P{};
   if (enumerate) {
-    psa::EnumParams P{};
     P.seq1 = c->d_seq1;
     P.len1 = c->len1;
     P.seq2_pool = b->d_pool;
@@ -819,8 +838,13 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     P.short_rows = b->d_short ? b->d_short + (size_t)par * (size_t)b->short_cap : nullptr;
     P.short_total = b->d_short ? b->d_counters + 1 + par : nullptr;
     P.short_rows_cap = b->short_cap;
+    P.has_short_ref = short_ref ? 1 : 0;
+    P.short_ref = short_ref ? *short_ref : 0;
     F.short_total = P.short_total;
     F.short_out = b->d_short_out;
+    F.short_empty_ok = short_ref ? 1 : 0;
+  }
+  if (enumerate && head) {
     // A pre-pass may fill a slab as soon as the last candidate loop that read it has finished,
     // so it runs beside the candidate loop of the pass before it (on the other slab) and, for
     // runs enqueued back to back, beside the candidate loop of the run before.
@@ -882,10 +906,16 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
       c->slab_reader_batch[buf] = b;
       last_loop[es] = sp.ev_e[buf];
     }
+    b->head_es = es;
+    b->head_last_loop[0] = last_loop[0];
+    b->head_last_loop[1] = last_loop[1];
+  }
+  if (enumerate && tail) {
     // locate and the records follow the last candidate loop on its stream; the candidate loops
     // of the next run start on the other stream, on the other copy of the accumulators
+    const int es = b->head_es;
     hipStream_t st_tail = c->st_enum[es];
-    if (last_loop[es ^ 1]) PSA_HIP(hipStreamWaitEvent(st_tail, last_loop[es ^ 1], 0));
+    if (b->head_last_loop[es ^ 1]) PSA_HIP(hipStreamWaitEvent(st_tail, b->head_last_loop[es ^ 1], 0));
     // runs of one batch write one set of records: this run's must land after those of a run
     // without enumeration enqueued just before it; and a run without the resolve stage, whose
     // record kernel also resets the resolve accumulators, after the resolve chain before it
@@ -929,14 +959,15 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     b->tail_recorded[par] = true;
     b->tail_stream[par] = es;
     *timed = true;
+    if (!resolve) b->enum_only_tail = b->ev_last;
   }
-  if ((resolve || !enumerate) && b->enum_only_tail) {
+  if (head && (resolve || !enumerate)) {
     // the record kernel of a run without the resolve stage (the run before this one) clears the
     // float32 half of the records and resets the resolve accumulators: this chain starts after it
-    PSA_HIP(hipStreamWaitEvent(c->st_res, b->enum_only_tail, 0));
+    if (b->enum_only_tail) PSA_HIP(hipStreamWaitEvent(c->st_res, b->enum_only_tail, 0));
+    b->enum_only_tail = nullptr;
   }
-  b->enum_only_tail = (enumerate && !resolve) ? b->ev_last : nullptr;
-  if (resolve) {
+  if (head && resolve) {
     psa::ResolveParams P{};
     P.seq1 = c->d_seq1;
     P.len1 = c->len1;
@@ -953,7 +984,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     if (const char *e = std::getenv("PSA_TIE_GRID")) tie_grid = std::max(1, std::min(8192, std::atoi(e)));  // tuning aid
     PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res, b->ev_res_first));
   }
-  if (resolve || !enumerate) {
+  if (head && (resolve || !enumerate)) {
     // the float32 half of the records is filled on the resolve stream, beside the enumeration;
     // a run without enumeration fills (clears) the other half here too
     F.which = enumerate ? PSA_STAGE_RESOLVE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
@@ -967,8 +998,19 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed) {
     b->res_recorded = true;
     PSA_HIP(psa::debug_sync("psa_finalize"));
   }
-  b->acc_ready = true;  // psa_finalize leaves the accumulators reset
+  if (tail) b->acc_ready = true;  // psa_finalize leaves the accumulators reset
   return PSA_OK;
+}
+
+// what psa_batch_wait needs to know about the run just enqueued
+static void mark_pending(psa_batch *b, uint32_t stages, bool timed, bool global_ref) {
+  b->pending = true;
+  b->pending_timed = timed;
+  // which record kernels this run has: the enumeration side's, the resolve side's, or both
+  b->pending_resolve = ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) || !timed;
+  b->pending_both = timed && (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
+  b->pending_short = timed && b->d_short != nullptr;
+  b->global_ref = global_ref;
 }
 
 int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
@@ -990,12 +1032,7 @@ int psa_batch_enqueue(psa_batch *b, uint32_t stages) {
     int st = enqueue_run(b, stages, &timed);
     if (st != PSA_OK) return st;
   }
-  b->pending = true;
-  b->pending_timed = timed;
-  // which record kernels this run has: the enumeration side's, the resolve side's, or both
-  b->pending_resolve = ((stages & PSA_STAGE_RESOLVE) && b->nfwd > 0) || !timed;
-  b->pending_both = timed && (stages & PSA_STAGE_RESOLVE) && b->nfwd > 0;
-  b->pending_short = timed && b->d_short != nullptr;
+  mark_pending(b, stages, timed, false);
   return PSA_OK;
 }
 
@@ -1064,9 +1101,11 @@ int psa_batch_wait(psa_batch *b) {
     const psa::ShortOut &so = b->h_short[i];
     if (r.status != PSA_OK || so.state != 1) continue;
     if (b->pending_both) {
-      if (r.enum_check == 1)
+      // (a shard that shortlisted against the maximum over all shards need not hold its own float32 answer
+      // inside that window: the replayed winners are compared after the combine, psa_batch_run_allgather)
+      if (r.enum_check == 1 && !b->global_ref)
         r.enum_check = (so.score_bits == r.score_bits && so.n == r.n && so.k == r.k && so.offset == r.offset) ? 2 : -2;
-    } else {
+    } else if (so.n > 0) {  // (a shard's list against the maximum over all shards can be complete and empty)
       r.n = so.n;
       r.k = so.k;
       r.offset = so.offset;
@@ -1136,62 +1175,259 @@ int psa_score_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s_begin,
   return st;
 }
 
+// ---- the answer path chosen by the host program ---------------------------------------
+int psa_parse_stages(const char *text, uint32_t *stages) {
+  if (!stages) return PSA_ERR_ARG;
+  if (!text || !*text || std::strcmp(text, "resolve") == 0) *stages = PSA_STAGE_RESOLVE;
+  else if (std::strcmp(text, "enumerate") == 0) *stages = PSA_STAGE_ENUMERATE;
+  else if (std::strcmp(text, "both") == 0) *stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  else {
+    g_err = std::string("stages must be resolve, enumerate or both, not '") + text + "'";
+    return PSA_ERR_ARG;
+  }
+  return PSA_OK;
+}
+
+int psa_score_batch_answer(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, uint32_t stages,
+                           psa_result *out, int *fallbacks) {
+  if (fallbacks) *fallbacks = 0;
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  if (stages != PSA_STAGE_ENUMERATE) {
+    int st = psa_score_batch(c, n, seq2, len2, stages, out);
+    if (st != PSA_OK || !(stages & PSA_STAGE_ENUMERATE)) return st;
+    for (int i = 0; i < n; ++i)
+      if (out[i].status == PSA_OK && out[i].enum_check < 0) {
+        g_err = "Seq2 #" + std::to_string(i + 1) + ": the enumeration stage and the resolve stage disagree (enum_check " +
+                std::to_string(out[i].enum_check) + ")";
+        return PSA_ERR_CHECK;
+      }
+    return PSA_OK;
+  }
+  // the enumeration stage alone: the answer comes from the replayed shortlist ...
+  psa_batch *b = nullptr;
+  int st = batch_build(c, n, seq2, len2, false, 0, 0, PSA_STAGE_ENUMERATE, &b);
+  if (st != PSA_OK) return st;
+  std::vector<int32_t> state((size_t)std::max(n, 1), 0);
+  st = psa_batch_run(b, PSA_STAGE_ENUMERATE);
+  if (st == PSA_OK) st = psa_batch_results(b, out);
+  if (st == PSA_OK) st = psa_batch_shortlist(b, nullptr, state.data());
+  psa_batch_destroy(b);
+  if (st != PSA_OK) return st;
+  // ... and where there is none (the list overflowed; the table does not fit the fixed-point range; the
+  // shortlist is switched off) from the resolve stage, for those Seq2 only
+  std::vector<int> idx;
+  for (int i = 0; i < n; ++i)
+    if (out[i].status == PSA_OK && out[i].candidates > 0 && state[(size_t)i] != 1) idx.push_back(i);
+  if (idx.empty()) return PSA_OK;
+  std::vector<const char *> s2(idx.size());
+  std::vector<int32_t> l2(idx.size());
+  for (size_t k = 0; k < idx.size(); ++k) {
+    s2[k] = seq2[idx[k]];
+    l2[k] = len2 ? len2[idx[k]] : (int32_t)std::strlen(seq2[idx[k]]);
+  }
+  std::vector<psa_result> r(idx.size());
+  st = psa_score_batch(c, (int)idx.size(), s2.data(), l2.data(), PSA_STAGE_RESOLVE, r.data());
+  if (st != PSA_OK) return st;
+  for (size_t k = 0; k < idx.size(); ++k) {
+    psa_result &o = out[idx[k]];
+    const psa_result &f = r[k];
+    if (f.status != PSA_OK) {
+      o.status = f.status;
+      continue;
+    }
+    o.n = f.n;
+    o.k = f.k;
+    o.offset = f.offset;
+    o.mutant_num = f.mutant_num;
+    o.score = f.score;
+    o.score_bits = f.score_bits;
+    std::memcpy(o.counts, f.counts, sizeof o.counts);
+  }
+  if (fallbacks) *fallbacks = (int)idx.size();
+  return PSA_OK;
+}
+
 // ---- one long pair over several ranks ----------------------------------------------
 // The reference has no such mode (it calls calc_best_score_CUDA once per Seq2, P/main.c:81,
 // :130, and each call walks all offsets); here the offsets [0, S) of one pair are cut into
 // nranks contiguous shards, this rank scores its shard on its GPU, the caller's all-gather
-// moves one record per rank, and every rank combines them to the same answer.
-// A resident one-Seq2 batch (this rank's offset shard) run once, then the exchange and combine.
-int psa_batch_run_allgather(psa_batch *b, int nranks, psa_allgather_fn allgather, void *comm, uint32_t stages,
-                            psa_result *out) {
-  if (!b || !out || nranks < 1 || (nranks > 1 && !allgather)) return PSA_ERR_ARG;
-  if (!b->ctx) return PSA_ERR_STATE;
-  if (b->n != 1) {
+// moves the shards' answers, and every rank combines them to the same record.
+namespace {
+
+// first exchange of an enumerating run: the shard's enumerated maximum (fixed point; every shard has the
+// same Seq2 and table, hence the same scale)
+struct ShardMax {
+  int32_t have;   // this shard enumerated candidates
+  int32_t score;
+  int32_t status;
+  int32_t pad_;
+};
+// last exchange: the shard's record and the winner of its replayed shortlist
+struct ShardMsg {
+  psa_result rec;
+  psa::ShortOut so;
+};
+static_assert(sizeof(ShardMax) == PSA_EXCHANGE_MAX_BYTES, "psa.h states this size");
+static_assert(sizeof(ShardMsg) == PSA_EXCHANGE_RECORD_BYTES, "psa.h states this size");
+
+bool replay_better(const psa::ShortOut &a, const psa::ShortOut &b) {  // highest score, then smallest (n, k, offset)
+  float fa, fb;
+  std::memcpy(&fa, &a.score_bits, sizeof fa);
+  std::memcpy(&fb, &b.score_bits, sizeof fb);
+  if (fa != fb) return fa > fb;
+  if (a.n != b.n) return a.n < b.n;
+  if (a.k != b.k) return a.k < b.k;
+  return a.offset < b.offset;
+}
+
+// The run of one shard and the exchanges around it.  b may be null and st0 an error: the rank then only
+// takes part in the collectives (the other ranks are already waiting in them) and reports its status.
+int run_shard_allgather(psa_batch *b, int st0, int nranks, psa_allgather_fn allgather, void *comm, uint32_t stages,
+                        psa_result *out) {
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
+  int st = st0;
+  if (st == PSA_OK && !b->ctx) st = PSA_ERR_STATE;
+  if (st == PSA_OK && b->n != 1) {
     g_err = "psa_batch_run_allgather: the batch must hold exactly one Seq2 (one shard of one pair)";
-    return PSA_ERR_ARG;
+    st = PSA_ERR_ARG;
   }
-  psa_result mine{};
-  int st = psa_batch_run(b, stages);
-  if (st == PSA_OK) st = psa_batch_results(b, &mine);
-  // A rank whose run failed still takes part in the collective (the others are already waiting
-  // in it) and reports the failure through its record.
+  const bool two_parts = nranks > 1 && (stages & PSA_STAGE_ENUMERATE);
+  if (!two_parts) {
+    if (st == PSA_OK) st = psa_batch_run(b, stages);
+  } else {
+    // candidate loops (and the resolve chain beside them); then the shards' enumerated maxima go round, and
+    // locate shortlists this shard against the maximum over all of them
+    ShardMax mx{};
+    bool timed = false;
+    if (st == PSA_OK) {
+      psa_ctx *c = b->ctx;
+      b->ran = b->pending = false;
+      auto head = [&]() -> int {
+        PSA_HIP(hipSetDevice(c->device));
+        int e = enqueue_run(b, stages, &timed, kPartHead);
+        if (e != PSA_OK) return e;
+        if ((stages & PSA_STAGE_ENUMERATE) && b->nchunks > 0) {
+          for (hipEvent_t ev : b->head_last_loop)
+            if (ev) PSA_HIP(hipEventSynchronize(ev));
+          unsigned long long key = 0ull;
+          const psa::SeqAcc *eacc = b->d_acc + (size_t)b->acc_par * (size_t)b->n;
+          PSA_HIP(hipMemcpy(&key, &eacc->enum_key, sizeof key, hipMemcpyDeviceToHost));
+          if (key != 0ull) {
+            mx.have = 1;
+            mx.score = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+          }
+        }
+        return PSA_OK;
+      };
+      st = head();
+      if (st != PSA_OK) b->acc_ready = false;
+    }
+    mx.status = st;
+    std::vector<ShardMax> all((size_t)nranks);
+    const bool comm_ok = allgather(&mx, all.data(), sizeof mx, comm) == 0;
+    int gref = INT32_MIN;
+    bool have = false;
+    for (const ShardMax &a : all)
+      if (comm_ok && a.have) {
+        gref = have ? std::max(gref, a.score) : a.score;
+        have = true;
+      }
+    if (st == PSA_OK) {
+      // (the second part is enqueued even after a failed exchange: it leaves the batch's accumulators reset)
+      st = enqueue_run(b, stages, &timed, kPartTail, have ? &gref : nullptr);
+      if (st == PSA_OK) {
+        mark_pending(b, stages, timed, have);
+        st = psa_batch_wait(b);
+      } else {
+        b->acc_ready = false;
+      }
+    }
+    if (!comm_ok) {
+      g_err = "psa_batch_run_allgather: the caller's all-gather reported a failure";
+      return PSA_ERR_COMM;
+    }
+  }
+  ShardMsg mine{};
+  if (st == PSA_OK) st = psa_batch_results(b, &mine.rec);
+  if (st == PSA_OK && b->pending_short) mine.so = b->h_short[0];
   if (st != PSA_OK) {
-    mine = psa_result{};
-    mine.status = st;
+    mine = ShardMsg{};
+    mine.rec.status = st;
   }
   if (nranks == 1) {  // what the combine returns for one part
-    *out = mine;
-    return st != PSA_OK ? st : mine.status;
+    *out = mine.rec;
+    return st != PSA_OK ? st : mine.rec.status;
   }
-  std::vector<psa_result> parts((size_t)nranks);
-  if (allgather(&mine, parts.data(), sizeof(psa_result), comm) != 0) {
+  std::vector<ShardMsg> msgs((size_t)nranks);
+  if (allgather(&mine, msgs.data(), sizeof(ShardMsg), comm) != 0) {
     g_err = "psa_batch_run_allgather: the caller's all-gather reported a failure";
     return PSA_ERR_COMM;
   }
-  return psa_combine_results(parts.data(), nranks, out);
+  std::vector<psa_result> parts((size_t)nranks);
+  for (int i = 0; i < nranks; ++i) parts[(size_t)i] = msgs[(size_t)i].rec;
+  st = psa_combine_results(parts.data(), nranks, out);
+  if (st != PSA_OK || !(stages & PSA_STAGE_ENUMERATE)) return st;
+  // The replayed shortlists of all shards together hold the reference's answer when every one of them is
+  // complete (each hangs below the maximum over all shards): their best winner against the combined record.
+  bool complete = true;
+  int best = -1;
+  for (int i = 0; i < nranks; ++i) {
+    const ShardMsg &m = msgs[(size_t)i];
+    if (m.rec.candidates == 0) continue;  // a shard without an offset
+    if (m.rec.enum_frac_bits < 0 || m.so.state != 1) {
+      complete = false;
+      continue;
+    }
+    if (m.so.n > 0 && (best < 0 || replay_better(m.so, msgs[(size_t)best].so))) best = i;
+  }
+  if (stages & PSA_STAGE_RESOLVE) {
+    if (out->enum_check == 1 && complete && out->n > 0) {
+      const psa::ShortOut *w = best >= 0 ? &msgs[(size_t)best].so : nullptr;
+      out->enum_check = (w && w->score_bits == out->score_bits && w->n == out->n && w->k == out->k && w->offset == out->offset) ? 2 : -2;
+    }
+  } else if (!complete || best < 0) {
+    // enumeration alone and some shard's list overflowed: no float32 answer (run the resolve stage)
+    out->n = out->k = out->offset = out->mutant_num = 0;
+    out->score = 0.0f;
+    out->score_bits = 0u;
+    std::memset(out->counts, 0, sizeof out->counts);
+  }
+  return PSA_OK;
+}
+
+}  // namespace
+
+int psa_batch_run_allgather(psa_batch *b, int nranks, psa_allgather_fn allgather, void *comm, uint32_t stages,
+                            psa_result *out) {
+  if (!b || !out || nranks < 1 || (nranks > 1 && !allgather)) return PSA_ERR_ARG;
+  return run_shard_allgather(b, PSA_OK, nranks, allgather, comm, stages, out);
 }
 
 int psa_score_range_allgather(psa_ctx *c, const char *seq2, int32_t len2, int rank, int nranks,
                               psa_allgather_fn allgather, void *comm, uint32_t stages, psa_result *out) {
+  // (errors of the call itself, the same on every rank: nobody enters a collective)
   if (!c || !seq2 || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !allgather))
     return PSA_ERR_ARG;
-  if (!c->have_seq1 || !c->have_table) return PSA_ERR_STATE;
-  const int64_t L2 = len2 >= 0 ? (int64_t)len2 : (int64_t)std::strlen(seq2);
-  const int64_t S = c->len1 - L2 + 3;  // P/cudaFunctions.cu:269
-  // (an invalid pair is invalid for every rank alike: any range lets the batch record the status)
-  const int64_t lo = S >= 1 ? S * rank / nranks : 0, hi = S >= 1 ? S * (rank + 1) / nranks : 1;
+  if (stages == 0) stages = PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE;
   psa_batch *b = nullptr;
-  int st = psa_batch_create_range(c, seq2, len2, lo, hi, &b);
-  if (st != PSA_OK) {
-    // still enter the collective, so that the other ranks do not wait for this one forever
-    psa_result mine{};
-    mine.status = st;
-    std::vector<psa_result> parts((size_t)nranks);
-    if (nranks > 1) (void)allgather(&mine, parts.data(), sizeof(psa_result), comm);
-    return st;
+  int st = PSA_OK;
+  // A context without Seq1 or table is this rank's own trouble: it still enters the collectives below, so
+  // that the other ranks do not wait for it forever, and all ranks return its status.
+  if (!c->have_seq1 || !c->have_table) {
+    g_err = "psa_score_range_allgather: Seq1 or the table is not set";
+    st = PSA_ERR_STATE;
+  } else {
+    const int64_t L2 = len2 >= 0 ? (int64_t)len2 : (int64_t)std::strlen(seq2);
+    const int64_t S = c->len1 - L2 + 3;  // P/cudaFunctions.cu:269
+    // (an invalid pair is invalid for every rank alike: any range lets the batch record the status)
+    const int64_t lo = S >= 1 ? S * rank / nranks : 0, hi = S >= 1 ? S * (rank + 1) / nranks : 1;
+    const char *one[1] = {seq2};
+    int32_t l[1] = {len2};
+    // (laid out for the stages that run: a resolve-only pair builds no chunk list, keys or slabs)
+    st = batch_build(c, 1, one, len2 >= 0 ? l : nullptr, true, lo, hi, stages, &b);
   }
-  st = psa_batch_run_allgather(b, nranks, allgather, comm, stages, out);
-  psa_batch_destroy(b);
+  st = run_shard_allgather(b, st, nranks, allgather, comm, stages, out);
+  if (b) psa_batch_destroy(b);
   return st;
 }
 
@@ -1250,8 +1486,13 @@ char *psa_calc_best_score(const char *seq1, const char *seq2, const float *comp_
   }
   psa_result r{};
   const char *one[1] = {seq2};
-  // the reference's answer is the float32 one; the enumeration stage is not needed for it
-  if ((st = psa_score_batch(ctx, 1, one, nullptr, PSA_STAGE_RESOLVE, &r)) != PSA_OK) die("psa_score_batch", st);
+  // PSA_STAGES = resolve (default: the float32 recurrence gives the reference's answer by itself), enumerate
+  // (every candidate scored by the candidate loop, as every call of the reference does,
+  // P/cudaFunctions.cu:290-296; the answer from the replayed shortlist, the resolve stage only where that
+  // overflowed) or both (the two must agree, or the call dies)
+  uint32_t stages = PSA_STAGE_RESOLVE;
+  if ((st = psa_parse_stages(std::getenv("PSA_STAGES"), &stages)) != PSA_OK) die("PSA_STAGES", st);
+  if ((st = psa_score_batch_answer(ctx, 1, one, nullptr, stages, &r, nullptr)) != PSA_OK) die("psa_score_batch_answer", st);
   if (r.status != PSA_OK) die("psa_calc_best_score", r.status);
   char *line = psa_format_result(&r);
   if (!line) die("psa_format_result", PSA_ERR_NOMEM);

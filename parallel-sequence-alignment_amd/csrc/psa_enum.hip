@@ -931,13 +931,16 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
     const unsigned long long ek = P.acc[ch.seq].enum_key;
     const unsigned long long ck = P.chunk_best[c];
     const int G = uni((int)((uint32_t)(ek >> 32) ^ 0x80000000u));
+    // the score the shortlist window hangs below: the Seq2's enumerated maximum, or for one shard of a
+    // long pair the maximum over all shards (never below the shard's own)
+    const int Gref = P.has_short_ref ? max(G, P.short_ref) : G;
     int slack = -1;
     if (P.short_rows) slack = uni(P.desc[ch.seq].enum_slack);
     // This kernel is the last reader of chunk_best in a run and leaves it zeroed for the next.
     // A wave that reads the zero instead of ck takes the same branch: ek is never 0, and the
     // zero decodes to the lowest value, outside every window.
     const bool exact = uni((int)(ek == ck));
-    bool near = uni((int)(slack >= 0 && (int)((uint32_t)(ck >> 32) ^ 0x80000000u) >= G - slack));
+    bool near = uni((int)(slack >= 0 && (int)((uint32_t)(ck >> 32) ^ 0x80000000u) >= Gref - slack));
     if (!exact && !near) {
       if (tid == 0) P.chunk_best[c] = 0ull;
       continue;
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
     if (tid == 0) P.chunk_best[c] = 0ull;
     enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);
     const int pstar = uni((int)(0xffffffffu - (uint32_t)ek));
-    const int T = G - slack;
+    const int T = Gref - slack;
     unsigned *const scount = &P.acc[ch.seq].short_count;
     unsigned long long best = ~0ull;
     for (int s = ch.s0; s < ch.s0 + ch.ns; ++s) {

@@ -252,11 +252,12 @@ const char *psa_strerror(int status) {
     case PSA_ERR_NOMEM: return "out of memory";
     case PSA_ERR_COMM: return "the caller's all-gather failed";
     case PSA_ERR_LIMIT: return "beyond the fixed capacity of the entry point that allocates nothing";
+    case PSA_ERR_CHECK: return "the enumeration stage and the resolve stage disagree";
     default: return "unknown status";
   }
 }
 
-const char *psa_version(void) { return "psa-hip 0.2 (gfx950)"; }
+const char *psa_version(void) { return "psa-hip 0.3 (gfx950)"; }
 
 int psa_combine_results(const psa_result *parts, int nparts, psa_result *out) {
   if (!parts || !out || nparts < 1) return PSA_ERR_ARG;

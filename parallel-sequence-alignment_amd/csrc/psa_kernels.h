@@ -28,6 +28,10 @@ struct EnumParams {
   ShortRow *short_rows;            // locate: this run's shortlist (null: none), ...
   unsigned *short_total;           // ... rows appended so far ...
   int short_rows_cap;              // ... and the list's capacity
+  // locate, one shard of a long pair: the shortlist window hangs below this fixed-point score (the maximum
+  // over ALL shards, exchanged between the ranks after the candidate loops) instead of the shard's own
+  int has_short_ref;
+  int short_ref;
 };
 
 // psa_enum_wave: one unit of work per (chunk, sub-run of its offsets, level).  Level w owns the
@@ -79,6 +83,7 @@ struct FinalParams {
   uint32_t which;   // PSA_STAGE_* bits: the halves of the records this launch fills
   unsigned *short_total;  // this run's shortlist row counter (null: no shortlist): reset by the enumeration half ...
   ShortOut *short_out;    // ... which reports the replayed winners here (pinned host memory)
+  int short_empty_ok;     // a list without a row is complete (state 1, no winner): shards of a long pair, see EnumParams::short_ref
 };
 
 int enum_class_of(int len2);          // -1 if len2 is too long

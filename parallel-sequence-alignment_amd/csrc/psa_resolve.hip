@@ -749,8 +749,19 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
     if (P.short_out) {
       ShortOut *so = P.short_out + i;
       const bool listed = uni(enum_ok && P.short_total && d.enum_slack >= 0);
-      const bool complete = uni(listed && ea.short_count <= (unsigned)kShortRowsPerSeq && ea.short_best != 0ull && ea.short_s != ~0u);
-      if (complete) {
+      const bool within = uni(listed && ea.short_count <= (unsigned)kShortRowsPerSeq);
+      const bool complete = uni(within && ea.short_best != 0ull && ea.short_s != ~0u);
+      if (within && !complete && P.short_empty_ok) {
+        // one shard of a long pair, window hung below the maximum over all shards: this shard holds no
+        // candidate inside it -- a complete list without a winner
+        if (tid == 0) {
+          so->score_bits = 0u;
+          so->n = so->k = so->offset = 0;
+          so->counts[0] = so->counts[1] = so->counts[2] = so->counts[3] = 0;
+          so->count = 0;
+          so->state = 1;
+        }
+      } else if (complete) {
         const int p = (int)(0xffffu - (uint32_t)((ea.short_best >> 16) & 0xffffu));
         const int q = (int)(0xffffu - (uint32_t)(ea.short_best & 0xffffu));
         const int s = (int)ea.short_s;

@@ -10,8 +10,12 @@
 // broadcast instead of one MPI_Send per Seq2, and the answers come back as fixed-size
 // records (one MPI_Gatherv) instead of formatted lines.  Buffers are dynamic.
 //
-//   mpiexec -np N psa_mpi [--dry-run] [--long-pair] [input.txt [output.txt]]
+//   mpiexec -np N psa_mpi [--dry-run] [--long-pair] [--stages=resolve|enumerate|both] [input.txt [output.txt]]
 //
+// --stages (default: PSA_STAGES in the environment, else resolve) chooses where the answer comes from:
+// the float32 recurrence alone, the candidate loop over every (offset, mutant) candidate -- what every
+// call of the reference runs, P/cudaFunctions.cu:290-296 -- with the float32 replay of the candidates near
+// its maximum, or both with the two required to agree.
 // A rank uses GPU (rank on its node) mod (GPUs of the node).  --dry-run does everything but
 // the scoring and prints which rank owns which Seq2: a check of the plumbing without a GPU.
 // --long-pair scores every Seq2 on all ranks together instead of giving each Seq2 to one rank:
@@ -28,21 +32,11 @@
 #include <vector>
 
 #include "psa.h"
+#include "psa_input.h"
 
 // the all-gather psa_score_range_allgather calls: comm points to the MPI communicator
 static int mpi_allgather(const void *send, void *recv, size_t bytes, void *comm) {
   return MPI_Allgather(send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, *(MPI_Comm *)comm) == MPI_SUCCESS ? 0 : 1;
-}
-
-static bool read_token(FILE *f, std::string &tok) {
-  tok.clear();
-  int c;
-  while ((c = std::fgetc(f)) != EOF && (c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f')) {
-  }
-  if (c == EOF) return false;
-  do tok.push_back((char)c);
-  while ((c = std::fgetc(f)) != EOF && !(c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'));
-  return true;
 }
 
 int main(int argc, char **argv) {
@@ -51,14 +45,23 @@ int main(int argc, char **argv) {
   MPI_Comm_rank(MPI_COMM_WORLD, &rank);
   MPI_Comm_size(MPI_COMM_WORLD, &size);
   bool dry = false, long_pair = false;
+  const char *stages_text = std::getenv("PSA_STAGES");
   std::vector<const char *> pos;
   for (int i = 1; i < argc; ++i) {
     if (std::strcmp(argv[i], "--dry-run") == 0)
       dry = true;
     else if (std::strcmp(argv[i], "--long-pair") == 0)
       long_pair = true;
+    else if (const char *w = psa_host::stages_option(argc, argv, i))
+      stages_text = w;
     else
       pos.push_back(argv[i]);
+  }
+  uint32_t stages = PSA_STAGE_RESOLVE;
+  if (psa_parse_stages(stages_text, &stages) != PSA_OK) {  // the same on every rank
+    if (rank == 0) std::fprintf(stderr, "psa_mpi: %s\n", psa_last_error_text());
+    MPI_Finalize();
+    return 2;
   }
   const char *in_name = pos.size() > 0 ? pos[0] : "input.txt";    // P/myProto.h:8
   const char *out_name = pos.size() > 1 ? pos[1] : "output.txt";  // P/myProto.h:9
@@ -71,19 +74,14 @@ int main(int argc, char **argv) {
   long long header[3] = {0, 0, -1};  // Seq1 length, number of Seq2, status
   FILE *out = nullptr;
   if (rank == 0) {
-    FILE *in = std::fopen(in_name, "r");
-    if (!in) {
+    std::printf("my rank is %d and i'm currently reading from the file\n", rank);  // P/main.c:37
+    psa_host::Input input;
+    if (!psa_host::read_input(in_name, input)) {
       std::printf("Error in opening the file\n");  // P/cFunctions.c:21-24
     } else {
-      std::string tok;
-      for (int i = 0; i < 4; ++i)
-        if (read_token(in, tok)) weights[i] = std::strtof(tok.c_str(), nullptr);
-      read_token(in, seq1);
-      int count = 0;
-      if (read_token(in, tok)) count = std::atoi(tok.c_str());
-      seq2.resize((size_t)(count > 0 ? count : 0));
-      for (auto &s : seq2) read_token(in, s);  // tokens after the count-th Seq2 are ignored, as in the reference
-      std::fclose(in);
+      std::memcpy(weights, input.weights, sizeof weights);
+      seq1.swap(input.seq1);
+      seq2.swap(input.seq2);
       out = dry ? nullptr : std::fopen(out_name, "w");
       if (!dry && !out) {
         std::printf("Error in opening the file\n");  // P/main.c:46-49
@@ -91,7 +89,7 @@ int main(int argc, char **argv) {
         header[0] = (long long)seq1.size();
         header[1] = (long long)seq2.size();
         header[2] = 0;
-        std::printf("num of seq2 = %d\n", count);  // P/main.c:51
+        std::printf("num of seq2 = %d\n", input.count);  // P/main.c:51
       }
     }
   }
@@ -149,7 +147,16 @@ int main(int argc, char **argv) {
     for (int i = 0; i < n && rc == 0; ++i) {
       psa_result res;
       st = psa_score_range_allgather(ctx, blob.data() + at, len2[(size_t)i], rank, size, mpi_allgather, &world,
-                                     PSA_STAGE_RESOLVE, &res);
+                                     stages, &res);
+      if (st == PSA_OK && res.status == PSA_OK && stages == PSA_STAGE_ENUMERATE && res.n == 0 && res.candidates > 0) {
+        // some shard's shortlist overflowed (every rank holds the same combined record and decides alike):
+        // the resolve stage gives the float32 answer of this pair
+        st = psa_score_range_allgather(ctx, blob.data() + at, len2[(size_t)i], rank, size, mpi_allgather, &world,
+                                       PSA_STAGE_RESOLVE, &res);
+      } else if (st == PSA_OK && res.status == PSA_OK && stages == (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE) &&
+                 res.enum_check < 0) {
+        st = PSA_ERR_CHECK;
+      }
       at += (size_t)len2[(size_t)i];
       if (st != PSA_OK || res.status != PSA_OK) {  // the same on every rank: the records were all-gathered
         if (rank == 0)
@@ -176,7 +183,7 @@ int main(int argc, char **argv) {
 
   // every rank computes the same split
   std::vector<int32_t> owner((size_t)n, 0);
-  psa_partition_stages(n, len2.data(), (int64_t)seq1.size(), size, PSA_STAGE_RESOLVE, owner.data());
+  psa_partition_stages(n, len2.data(), (int64_t)seq1.size(), size, stages, owner.data());
   std::vector<std::string> mine_s;
   std::vector<int> mine_idx;
   {
@@ -190,6 +197,7 @@ int main(int argc, char **argv) {
     }
   }
   std::vector<char>().swap(blob);
+  if (!dry) std::printf("proc[%d] portion = %d\n", rank, (int)mine_s.size());  // P/main.c:64, :113
 
   // score my share on the GPU that goes with my place on this node
   std::vector<psa_result> mine_r(mine_s.size());
@@ -207,7 +215,7 @@ int main(int argc, char **argv) {
         ptr.push_back(s.c_str());
         lens.push_back((int32_t)s.size());
       }
-      st = psa_score_batch(ctx, (int)ptr.size(), ptr.data(), lens.data(), PSA_STAGE_RESOLVE, mine_r.data());
+      st = psa_score_batch_answer(ctx, (int)ptr.size(), ptr.data(), lens.data(), stages, mine_r.data(), nullptr);
     }
     if (st != PSA_OK)
       std::fprintf(stderr, "psa_mpi: rank %d: %s (%s)\n", rank, psa_strerror(st), psa_last_error_text());

@@ -95,6 +95,9 @@ def lib():
     L.psa_batch_destroy.restype = None
     L.psa_score_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.c_uint32, C.POINTER(Result)]
     L.psa_score_range.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(Result)]
+    L.psa_score_batch_answer.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.c_uint32, C.POINTER(Result),
+                                         C.POINTER(C.c_int)]
+    L.psa_parse_stages.argtypes = [C.c_char_p, C.POINTER(C.c_uint32)]
     L.psa_combine_results.argtypes = [C.POINTER(Result), C.c_int, C.POINTER(Result)]
     L.psa_calc_best_score.argtypes = [C.c_char_p, C.c_char_p, f32p]
     L.psa_calc_best_score.restype = C.c_void_p  # malloc'd char*, freed below
@@ -208,6 +211,14 @@ def cost_estimate(len2, len1, stages=0):
     return lib().psa_cost_estimate(len2, len1, stages)
 
 
+def parse_stages(text):
+    """"resolve" | "enumerate" | "both" (what PSA_STAGES and the host programs' --stages take) -> STAGE_* bits;
+    None or "" -> STAGE_RESOLVE."""
+    out = C.c_uint32()
+    _check(lib().psa_parse_stages(None if text is None else _bytes(text), C.byref(out)), "psa_parse_stages")
+    return out.value
+
+
 def default_device():
     """GPU for this process: PSA_DEVICE, else the launcher's local rank modulo the GPU count, else 0."""
     return lib().psa_default_device()
@@ -308,6 +319,21 @@ class Context:
             return b.run(stages)
         finally:
             b.close()
+
+    def score_batch_answer(self, seq2s, stages=STAGE_RESOLVE):
+        """psa_score_batch_answer: the reference's answer for every Seq2 by the path `stages` names -- the
+        resolve stage, the enumeration stage (candidate loop + float32 replay of its shortlist, the resolve
+        stage only for the Seq2 whose list overflowed) or both, which must agree.  Returns (records, number of
+        Seq2 that fell back to the resolve stage)."""
+        bs = [_bytes(s) for s in seq2s]
+        n = len(bs)
+        arr = (C.c_char_p * max(n, 1))(*bs)
+        lens = np.array([len(b) for b in bs], dtype=np.int32)
+        out = (Result * max(n, 1))()
+        fb = C.c_int()
+        _check(lib().psa_score_batch_answer(self._h, n, arr, lens.ctypes.data_as(C.POINTER(C.c_int32)), stages, out,
+                                            C.byref(fb)), "psa_score_batch_answer")
+        return list(out)[:n], fb.value
 
     def score_range_allgather(self, seq2, rank, nranks, allgather=None, stages=STAGE_BOTH):
         """One long pair over nranks ranks (psa_score_range_allgather): this rank's offset shard is

@@ -476,10 +476,54 @@ def test_offset_shards_more_than_offsets(psa, ctx, oracle):
     assert psa.combine_results(parts[:3]).n == 0  # only empty shards: a record without a candidate
 
 
+class _ThreadRanks:
+    """nranks threads of one process as the ranks of a job: every rank has its own context on GPU 0, and the
+    all-gather callback meets the other ranks at a barrier (the library calls release the interpreter lock)."""
+
+    def __init__(self, nranks):
+        import threading
+        self.n = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.slots = [None] * nranks
+        self.calls = [[] for _ in range(nranks)]
+
+    def gather(self, rank):
+        def fn(send):
+            self.calls[rank].append(len(send))
+            self.slots[rank] = bytes(send)
+            self.barrier.wait(timeout=120)
+            out = b"".join(self.slots)
+            self.barrier.wait(timeout=120)
+            return out
+        return fn
+
+    def run(self, work):
+        """work(rank, gather callback) on every rank; returns the list of results (exceptions re-raised)."""
+        import threading
+        out, err = [None] * self.n, [None] * self.n
+
+        def body(r):
+            try:
+                out[r] = work(r, self.gather(r))
+            except BaseException as e:  # noqa: B902 -- reported by the main thread
+                err[r] = e
+                self.barrier.abort()
+        th = [threading.Thread(target=body, args=(r,)) for r in range(self.n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+
 def test_long_pair_allgather_entry(psa, ctx, oracle):
-    """psa_score_range_allgather / psa_batch_run_allgather: the shard of `rank`, one all-gather through
-    the caller's callback, the combine.  The other ranks are played by the callback, which scores
-    their shards on the same GPU."""
+    """psa_score_range_allgather / psa_batch_run_allgather with 1, 2 and 3 ranks (threads, one context each):
+    an enumerating run exchanges the shards' enumerated maxima after the candidate loops, every shard
+    shortlists against the maximum over all shards, and the replayed winners of all shards together give
+    the combined float32 answer -- enum_check 2 at every rank count, as on one GPU."""
     from psa_amd import dist as pdist
     seq1, seq2s = synth_problem(23, 4000, [700])
     seq2 = seq2s[0]
@@ -489,31 +533,90 @@ def test_long_pair_allgather_entry(psa, ctx, oracle):
     ctx.set_weights(w)
     whole = ctx.score_batch([seq2])[0]
     check_against_oracle(oracle, seq1, [seq2], table, [whole])
+    assert whole.enum_check == 2
     S = len(seq1) - len(seq2) + 3
-    for nranks in (1, 3):
-        for rank in range(nranks):
-            calls = []
+    full = lambda r: (r.key(), r.enum_key(), tuple(r.counts), tuple(r.enum_counts), r.candidates, r.mutant_num)
+    got1 = ctx.score_range_allgather(seq2, 0, 1, None)
+    assert full(got1) == full(whole) and got1.enum_check == 2
+    for nranks in (2, 3):
+        for stages, sizes in ((psa.STAGE_BOTH, [16, 136]), (psa.STAGE_RESOLVE, [136]), (psa.STAGE_ENUMERATE, [16, 136])):
+            ranks = _ThreadRanks(nranks)
 
-            stages = [psa.STAGE_BOTH]
+            def work(rank, gather, stages=stages, nranks=nranks):
+                c = psa.Context(0)
+                try:
+                    c.set_seq1(seq1)
+                    c.set_weights(w)
+                    one_shot = c.score_range_allgather(seq2, rank, nranks, gather, stages)
+                    b = c.batch_range(seq2, *pdist.offset_shard(S, rank, nranks))
+                    resident = [b.run_allgather(nranks, gather, stages) for _ in range(2)]  # resident shard, run twice
+                    b.close()
+                    return [one_shot] + resident
+                finally:
+                    c.close()
+            per_rank = ranks.run(work)
+            assert all(c == sizes * 3 for c in ranks.calls), ranks.calls
+            for recs in per_rank:
+                for r in recs:
+                    assert r.status == 0 and r.candidates == whole.candidates
+                    assert r.key() == whole.key() and tuple(r.counts) == tuple(whole.counts) and r.mutant_num == whole.mutant_num
+                    if stages & psa.STAGE_ENUMERATE:
+                        assert r.enum_key() == whole.enum_key() and tuple(r.enum_counts) == tuple(whole.enum_counts)
+                    else:
+                        assert r.enum_n == 0
+                    assert r.enum_check == (2 if stages == psa.STAGE_BOTH else 0), r.enum_check
+            assert all(bytes(recs[0]) == bytes(per_rank[0][0]) for recs in per_rank)  # every rank the same record
+    # the hit sits in one shard; the others must list nothing instead of overflowing on their own near-maxima:
+    # a planted hit in a long random pair, 4 ranks
+    seq1b, seq2b = synth_problem(4, 60000, [3000])
+    ranks = _ThreadRanks(4)
 
-            def gather(send, rank=rank, nranks=nranks):
-                calls.append(len(send))
-                parts = []
-                for r in range(nranks):
-                    parts.append(send if r == rank else
-                                 bytes(ctx.score_range(seq2, *pdist.offset_shard(S, r, nranks), stages[0])))
-                return b"".join(parts)
-            got = ctx.score_range_allgather(seq2, rank, nranks, gather if nranks > 1 else None)
-            assert (got.key(), got.enum_key(), tuple(got.counts), got.candidates) == \
-                (whole.key(), whole.enum_key(), tuple(whole.counts), whole.candidates)
-            assert calls == ([96] if nranks > 1 else [])
-            b = ctx.batch_range(seq2, *pdist.offset_shard(S, rank, nranks))
-            stages[0] = psa.STAGE_RESOLVE
-            for _ in range(2):  # resident shard, run twice
-                got = b.run_allgather(nranks, gather if nranks > 1 else None, psa.STAGE_RESOLVE)
-                assert got.key() == whole.key() and got.enum_n == 0
-            b.close()
+    def work_b(rank, gather):
+        c = psa.Context(0)
+        try:
+            c.set_seq1(seq1b)
+            c.set_weights(w)
+            return c.score_range_allgather(seq2b[0], rank, 4, gather, psa.STAGE_BOTH)
+        finally:
+            c.close()
+    recs = ranks.run(work_b)
+    ctx.set_seq1(seq1b)
+    whole_b = ctx.score_batch([seq2b[0]])[0]
+    check_against_oracle(oracle, seq1b, [seq2b[0]], table, [whole_b])
+    assert all(full(r) == full(whole_b) and r.enum_check == 2 for r in recs), [r.enum_check for r in recs]
+    # every shard overflows (all-same sequences): bound only, and an enumeration-only run has no float32 answer
+    ranks = _ThreadRanks(2)
+
+    def work_c(rank, gather):
+        c = psa.Context(0)
+        try:
+            c.set_seq1("A" * 3000)
+            c.set_weights(w)
+            return [c.score_range_allgather("A" * 400, rank, 2, gather, st) for st in (psa.STAGE_BOTH, psa.STAGE_ENUMERATE)]
+        finally:
+            c.close()
+    for both, only in ranks.run(work_c):
+        assert both.key() == oracle.fast("A" * 3000, "A" * 400, table).as_tuple() and both.enum_check == 1
+        assert only.n == 0 and only.score_bits == 0 and only.enum_key() == both.enum_key()
+    # a rank whose context is not ready still takes part in every exchange, and all ranks return its status
+    ranks = _ThreadRanks(2)
+
+    def work_d(rank, gather):
+        c = psa.Context(0)
+        try:
+            if rank == 0:
+                c.set_seq1(seq1)
+                c.set_weights(w)
+            try:
+                c.score_range_allgather(seq2, rank, 2, gather, psa.STAGE_BOTH)
+            except psa.PsaError as e:
+                return e.status
+            return 0
+        finally:
+            c.close()
+    assert ranks.run(work_d) == [7, 7] and ranks.calls == [[16, 136], [16, 136]]
     # a callback that fails is reported, not swallowed
+    ctx.set_seq1(seq1)
     with pytest.raises(psa.PsaError) as ei:
         ctx.score_range_allgather(seq2, 0, 2, lambda send: b"")
     assert ei.value.status == 9
@@ -521,6 +624,48 @@ def test_long_pair_allgather_entry(psa, ctx, oracle):
     with pytest.raises(psa.PsaError) as ei:
         ctx.score_range_allgather("A", 0, 1, None)
     assert ei.value.status == 2
+
+
+def test_answer_path_switch(psa, ctx, oracle, golden):
+    """psa_score_batch_answer: the answer path a host program chooses -- resolve, enumerate (candidate loop +
+    float32 replay of its shortlist; the resolve stage only for the Seq2 whose list overflowed) or both --
+    gives the reference's answer for every Seq2 either way; a table with a NaN or an infinity is refused."""
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    assert [psa.parse_stages(t) for t in (None, "", "resolve", "enumerate", "both")] == [2, 2, 2, 1, 3]
+    with pytest.raises(psa.PsaError):
+        psa.parse_stages("everything")
+    seq1, seq2s = synth_problem(41, 2500, [2000, 700, 301, 64, 5, 2])
+    seq2s += ["A" * 300, "AB" * 150]  # every row ties: the shortlist overflows
+    seq1 = seq1[:1200] + "A" * 400 + seq1[1200:]
+    ctx.set_seq1(seq1)
+    ctx.set_weights(w)
+    want = [oracle.fast(seq1, s, table) for s in seq2s]
+    for stages in (psa.STAGE_RESOLVE, psa.STAGE_ENUMERATE, psa.STAGE_BOTH):
+        res, fallbacks = ctx.score_batch_answer(seq2s, stages)
+        for r, o, s in zip(res, want, seq2s):
+            assert r.status == 0 and r.key() == o.as_tuple() and r.mutant_num == o.mutant_num, (stages, len(s), r.key(), o.as_tuple())
+            assert tuple(r.counts) == oracle.counts(seq1, s, r.offset, r.n, r.k)
+            assert (r.enum_n > 0) == bool(stages & psa.STAGE_ENUMERATE)
+        assert (fallbacks >= 2) if stages == psa.STAGE_ENUMERATE else fallbacks == 0, fallbacks
+    res, fallbacks = ctx.score_batch_answer(["ABCD", "A", "AB1D"], psa.STAGE_ENUMERATE)
+    assert [r.status for r in res] == [0, 2, 4] and res[0].n >= 1
+    # the reference's sample input through the enumeration stage alone: no fallback needed
+    case = golden[0]
+    ctx.set_seq1(case["seq1"])
+    ctx.set_weights(parse_weights(case["weights"]))
+    res, fallbacks = ctx.score_batch_answer(case["seq2"], psa.STAGE_ENUMERATE)
+    assert fallbacks == 0
+    assert [r.key() for r in res] == [(e["n"], e["k"], e["offset"], e["bits"]) for e in case["expected"]]
+    # non-finite table entries
+    for bad in (np.nan, np.inf, -np.inf):
+        t = table.copy()
+        t[77] = bad
+        with pytest.raises(psa.PsaError) as ei:
+            ctx.set_table(t)
+        assert ei.value.status == 1
+    ctx.set_table(table)
+    assert ctx.score_batch(case["seq2"][:1])[0].status == 0  # the context still holds a valid table
 
 
 def test_context_guards(psa):
@@ -698,6 +843,69 @@ def test_reference_host_program_bound_to_libpsa_hip(psa, golden, tmp_path):
         assert len(picks) == 2, r.stderr[-2000:]
         ngpu = int(picks[0][1])
         assert sorted(int(p[0]) for p in picks) == ([0, 1] if ngpu >= 2 else [0, 0])
+
+
+def test_stages_switch_through_the_host_programs(psa, golden, tmp_path):
+    """PSA_STAGES / --stages on the boundary: the reference's own host program (main.c + cFunctions.c,
+    unmodified, bound to psa_calc_best_score), psa_host, psa_mpi and psa_mpi --long-pair write the same
+    output.txt whether the answer comes from the resolve stage, from the candidate loop's replayed shortlist
+    (enumerate) or from both; psa_host --sequential-format prints the Sequential Solution's stdout."""
+    import os
+    import shutil
+    import subprocess
+    from shutil import which
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "parallel-sequence-alignment_amd")
+    mpiexec = which("/opt/conda/bin/mpiexec") or which("mpiexec")
+    refhost = os.path.join(root, "oracle", "_ref", "refhost_psa")
+    names = ("ref_input.txt", "ref_s_input3.txt", "ref_p_input1.txt")
+    for name in names:
+        case = [c for c in golden if c["name"] == name][0]
+        want = _expected_lines(psa, case)
+        inp = os.path.join(root, "tests", "golden", "inputs", name)
+        for stages in ("both", "enumerate"):
+            tag = "%s_%s" % (stages, name)
+            out = tmp_path / ("host_" + tag)
+            r = subprocess.run([os.path.join(pkg, "psa_host"), "--stages=" + stages, inp, str(out), "1"],
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            assert open(out).read().splitlines(keepends=True) == want
+            if mpiexec and os.path.exists(os.path.join(pkg, "psa_mpi")):
+                for extra in ([], ["--long-pair"]):
+                    out = tmp_path / ("mpi_%s_%s" % ("lp" if extra else "list", tag))
+                    r = subprocess.run([mpiexec, "-np", "2", os.path.join(pkg, "psa_mpi"), "--stages", stages] + extra +
+                                       [inp, str(out)], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+                    assert r.returncode == 0, r.stderr + r.stdout
+                    assert open(out).read().splitlines(keepends=True) == want
+            if mpiexec and os.path.exists(refhost):
+                work = tmp_path / ("refhost_" + tag)
+                work.mkdir()
+                shutil.copy(inp, work / "input.txt")
+                env = dict(os.environ, PSA_STAGES=stages)
+                env.pop("PSA_DEVICE", None)
+                r = subprocess.run([mpiexec, "-np", "2", refhost], capture_output=True, text=True, timeout=300,
+                                   cwd=str(work), env=env)
+                assert r.returncode == 0, r.stderr + r.stdout
+                assert open(work / "output.txt").read().splitlines(keepends=True) == want
+                assert all(line in r.stdout for line in want)  # the echo of P/cudaFunctions.cu:321
+    # a misspelt switch is an error, not a silent default
+    r = subprocess.run([os.path.join(pkg, "psa_host"), "--stages=all", inp, str(tmp_path / "x")], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 2 and "resolve, enumerate or both" in r.stderr
+    # the Sequential Solution's stdout (S/main.c:82, :87) as the compiled reference printed it for its input.txt
+    ref = [l for l in open(os.path.join(root, "tests", "golden", "ref_input_reference_stdout.txt")).read().splitlines(keepends=True)
+           if not l.startswith("PSA_REF_BITS")]
+    inp = os.path.join(root, "tests", "golden", "inputs", "ref_input.txt")
+    for stages in ("resolve", "enumerate"):
+        out = tmp_path / ("seqfmt_" + stages)
+        r = subprocess.run([os.path.join(pkg, "psa_host"), "--sequential-format", "--stages=" + stages, inp, str(out)],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.splitlines(keepends=True) == ref
+        assert open(out).read() == ""  # S/main.c:28-32 opens output.txt and never writes it
+    from psa_amd import host
+    lines = host.run(inp, str(tmp_path / "py_seq"), echo=False, stages=psa.STAGE_ENUMERATE, sequential_format=True)
+    assert lines == ref[:-1]
 
 
 def test_config3_shape_small(psa, ctx, oracle):

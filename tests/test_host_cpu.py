@@ -135,7 +135,9 @@ def test_mpi_host_split_dry_run(psa, np_ranks, tmp_path):
                        capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     lines = r.stdout.splitlines()
-    assert lines[0] == "num of seq2 = 4"
+    assert lines[0] == "my rank is 0 and i'm currently reading from the file"  # P/main.c:37
+    lines = lines[1:]
+    assert lines[0] == "num of seq2 = 4"  # P/main.c:51
     got = [re.match(r"Seq2 #(\d+) \((\d+) characters\) -> rank (\d+)", l).groups() for l in lines[1:5]]
     lens = [138, 1202, 466, 377]
     assert [int(g[0]) for g in got] == [1, 2, 3, 4] and [int(g[1]) for g in got] == lens
@@ -157,4 +159,4 @@ def test_mpi_host_more_ranks_than_seq2(psa, tmp_path):
                        cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     lines = r.stdout.splitlines()
-    assert lines[0] == "num of seq2 = 2" and len([l for l in lines if l.startswith("Seq2 #")]) == 2
+    assert lines[1] == "num of seq2 = 2" and len([l for l in lines if l.startswith("Seq2 #")]) == 2
