@@ -252,7 +252,8 @@ int psa_batch_run_allgather(psa_batch *shard, int nranks, psa_allgather_fn allga
  * makes no hipMalloc, hipFree or other allocating call.
  * Limits: len1 <= PSA_NOALLOC_MAX_SEQ1 (else PSA_ERR_LIMIT), len2 <= PSA_MAX_SEQ2.  The
  * enumeration fields of the record are cleared (enum_frac_bits = -1).  A character outside
- * 'A'..'Z' is found on the device: the record then has status PSA_ERR_RESIDUE and nothing else.
+ * 'A'..'Z' is found on the device: the record then has status PSA_ERR_RESIDUE and nothing else;
+ * likewise a table entry that is not finite (the requirement of psa_set_table): PSA_ERR_ARG.
  * All calls on one GPU share that GPU's array: calls whose kernels could overlap (two streams,
  * two threads) race; issue them on one stream or order them with events.
  * psa_noalloc_init (optional; otherwise done by the first call on each device) looks up the

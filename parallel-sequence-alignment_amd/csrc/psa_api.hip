@@ -980,6 +980,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
     P.active = b->d_active;
     P.nactive = b->d_counters;
     P.pchunks = (b->max_len2 + 255) / 256;
+    P.one_seq = b->n == 1 ? 1 : 0;
     int tie_grid = std::max(512, std::min(8192, b->nvalid * P.pchunks));
     if (const char *e = std::getenv("PSA_TIE_GRID")) tie_grid = std::max(1, std::min(8192, std::atoi(e)));  // tuning aid
     PSA_HIP(psa::launch_resolve(P, b->nfwd, b->max_len2, tie_grid, c->st_res, b->ev_res_first));

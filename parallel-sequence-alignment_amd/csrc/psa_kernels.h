@@ -63,6 +63,7 @@ struct ResolveParams {
   ActiveOffset *active;  // offsets whose maximum equals their Seq2's maximum
   unsigned *nactive;
   int pchunks;           // ceil(max len2 / 256)
+  int one_seq;           // the batch holds a single Seq2: what is known about it prunes whole blocks of the tie kernels
   // replay of the enumeration stage's shortlist (launch_short_replay only)
   ShortRow *short_rows;
   const unsigned *short_total;

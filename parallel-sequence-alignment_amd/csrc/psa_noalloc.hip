@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void psa_na_setup(NaSetup P) {
   unsigned char *ct = P.base + kOffClass;
   for (int64_t i = gid; i < kDevTable; i += gsz) {
     const int b = (int)(i / kRowStride), a = (int)(i % kRowStride);
-    tt[i] = (a < 26 && b < 26) ? P.table[a * 26 + b] : 0.0f;
+    const float v = (a < 26 && b < 26) ? P.table[a * 26 + b] : 0.0f;
+    if (!isfinite(v)) atomicOr(&cnt[1], 2u);  // the kernels' maxima are built on finite entries (as psa_set_table checks)
+    tt[i] = v;
     ct[i] = P.cls[i];
   }
   FwdBlock *fwd = (FwdBlock *)(P.base + kOffFwd);
@@ -140,8 +142,9 @@ __global__ __launch_bounds__(256) void psa_na_setup(NaSetup P) {
   }
 }
 
-// cnt[1] is cleared by the previous call's epilogue (and starts at zero with the code object);
-// it cannot be cleared by psa_na_setup itself, whose blocks set it in no particular order.
+// cnt[1], the invalid-residue flag, is cleared on the caller's stream before psa_na_setup (whose blocks
+// set it in no particular order, so it cannot clear it itself): a call that failed half-way, or was
+// abandoned, leaves nothing behind for the next one.
 __global__ void psa_na_epilogue(unsigned char *base, psa_result *out) {
   unsigned *cnt = (unsigned *)(base + kOffCnt);
   if (cnt[1]) {
@@ -149,9 +152,8 @@ __global__ void psa_na_epilogue(unsigned char *base, psa_result *out) {
     memset(&r, 0, sizeof r);
     r.enum_frac_bits = -1;
     r.enum_exact = -1;
-    r.status = PSA_ERR_RESIDUE;
+    r.status = (cnt[1] & 1u) ? PSA_ERR_RESIDUE : PSA_ERR_ARG;  // bit 0: a character outside 'A'..'Z'; bit 1: a table entry not finite
     *out = r;
-    cnt[1] = 0u;
   }
 }
 
@@ -206,15 +208,24 @@ int psa_noalloc_init(void) {
 int psa_score_range_noalloc(const char *d_seq1, int64_t len1, const char *d_seq2, int32_t len2,
                             const float *d_table, int64_t s_begin, int64_t s_end, void *stream, psa_result *d_out) {
   using namespace psa;
-  if (!d_seq1 || !d_seq2 || !d_table || !d_out) return PSA_ERR_ARG;
-  if (len1 < 1) return PSA_ERR_ARG;
+  g_na_err.clear();  // the text belongs to the most recent call on this thread
+  if (!d_seq1 || !d_seq2 || !d_table || !d_out || len1 < 1) {
+    g_na_err = "psa_score_range_noalloc: null pointer or empty Seq1";
+    return PSA_ERR_ARG;
+  }
   if (len1 > kNaMaxLen1) {
     g_na_err = "psa_score_range_noalloc: Seq1 is longer than PSA_NOALLOC_MAX_SEQ1 characters, the fixed capacity of "
                "this entry point (use psa_score_range, which allocates what it needs)";
     return PSA_ERR_LIMIT;
   }
-  if (len2 < 2) return PSA_ERR_SEQ2_SHORT;
-  if (len2 > PSA_MAX_SEQ2 || (int64_t)len2 - 2 > len1) return PSA_ERR_SEQ2_LONG;
+  if (len2 < 2) {
+    g_na_err = "psa_score_range_noalloc: Seq2 shorter than 2 characters";
+    return PSA_ERR_SEQ2_SHORT;
+  }
+  if (len2 > PSA_MAX_SEQ2 || (int64_t)len2 - 2 > len1) {
+    g_na_err = "psa_score_range_noalloc: Seq2 longer than Seq1 + 2 or than PSA_MAX_SEQ2";
+    return PSA_ERR_SEQ2_LONG;
+  }
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) {
     g_na_err = "no HIP device visible";
@@ -239,13 +250,20 @@ int psa_score_range_noalloc(const char *d_seq1, int64_t len1, const char *d_seq2
   A.s_begin = (int32_t)(empty ? 0 : sb);
   A.s_end = (int32_t)(empty ? 0 : se);
   A.nfwd = empty ? 0 : (int32_t)((se - sb + kFwdOffsets - 1) / kFwdOffsets);
-  if ((size_t)A.nfwd > kNaMaxFwd) return PSA_ERR_LIMIT;  // cannot happen: len1 is within the capacity
+  if ((size_t)A.nfwd > kNaMaxFwd) {  // cannot happen: len1 is within the capacity
+    g_na_err = "psa_score_range_noalloc: more forward blocks than the fixed capacity";
+    return PSA_ERR_LIMIT;
+  }
   for (int b = 0; b < 27; ++b)
     for (int a = 0; a < kRowStride; ++a)
       A.cls[b * kRowStride + a] = (a < 26 && b < 26) ? (unsigned char)residue_class_code(a, b) : (unsigned char)3;
   const int setup_blocks = (int)((len1 + 255) / 256 > 1024 ? 1024 : (len1 + 255) / 256);
-  hipLaunchKernelGGL(psa_na_setup, dim3(setup_blocks), dim3(256), 0, st_, A);
-  hipError_t e = hipGetLastError();
+  // (a memset node on the caller's stream: allocates nothing, and may be captured into a graph)
+  hipError_t e = hipMemsetAsync(base + kOffCnt + sizeof(unsigned), 0, sizeof(unsigned), st_);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(psa_na_setup, dim3(setup_blocks), dim3(256), 0, st_, A);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = debug_sync("psa_na_setup");
   if (e == hipSuccess && !empty) {
     ResolveParams P{};
@@ -260,6 +278,7 @@ int psa_score_range_noalloc(const char *d_seq1, int64_t len1, const char *d_seq2
     P.active = (ActiveOffset *)(base + kOffActive);
     P.nactive = (unsigned *)(base + kOffCnt);
     P.pchunks = (len2 + 255) / 256;
+    P.one_seq = 1;
     e = launch_resolve(P, A.nfwd, len2, 512, st_, nullptr);
   }
   if (e == hipSuccess) {

@@ -408,22 +408,33 @@ __global__ __launch_bounds__(256) void psa_first_p(ResolveParams P) {
   const unsigned nact = *P.nactive;
   const long long nitems = (long long)nact * P.pchunks;
   PSA_TS()
+  // Items in slice-major order: every active offset's first 256 positions, then every offset's second 256,
+  // and so on, so that a block's items never go back to a lower slice.  With thousands of offsets tied at the
+  // maximum (low-entropy inputs: every offset of an all-same pair) the first items to finish find a small p,
+  // nearly every other item is skipped, and in a one-Seq2 batch a block that meets a slice at or above the
+  // known p is done with all its items.
   for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
     ActiveOffset ao;
-    ao.seq = uni(P.active[item / P.pchunks].seq);
-    ao.s = uni(P.active[item / P.pchunks].s);
-    const int pc = (int)(item % P.pchunks);
+    const long long ai = item % nact;
+    ao.seq = uni(P.active[ai].seq);
+    ao.s = uni(P.active[ai].s);
+    const int pc = (int)(item / nact);
     // (requested together with the descriptor: one memory round trip, not three)
-    const int known_p = tid == 0 ? P.acc[ao.seq].res_p : 0;
+    // (an agent-scope load: a plain one can be served from this CU's vector cache, which other CUs' atomics
+    // never refresh -- a block whose own items find nothing would go on seeing the value it read first)
+    const int known_p = tid == 0 ? __hip_atomic_load(&P.acc[ao.seq].res_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const float fstar = key2f(P.acc[ao.seq].res_key);
     const SeqDesc d = load_desc(P.desc + ao.seq);
     const int L2 = d.len2;
     const int p0 = pc * 256;
     if (p0 > L2 - 2) continue;
     __syncthreads();
-    if (tid == 0) skip_flag[0] = p0 > known_p;  // a smaller p is already known
+    if (tid == 0) skip_flag[0] = p0 >= known_p;  // a p at or below this slice's first is already known
     __syncthreads();
-    if (uni(skip_flag[0])) continue;  // one decision for the whole block
+    if (uni(skip_flag[0])) {  // one decision for the whole block
+      if (P.one_seq) break;   // later items of this block sit in the same or a higher slice of the same Seq2
+      continue;
+    }
     float *d0 = T + kDevTable;
     f2 *d21 = (f2 *)(d0 + tie_d0_len(L2));
     PSA_TS()
@@ -506,7 +517,8 @@ __device__ __forceinline__ void first_q_body(const ResolveParams &P) {
   PSA_TS()
   for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
     ActiveOffset ao;
-    const int qc = (int)(item % P.pchunks);
+    // (the tie offsets in slice-major order, like psa_first_p; the shortlist's rows row by row)
+    const int qc = ROWS ? (int)(item % P.pchunks) : (int)(item / nact);
     unsigned long long known = ~0ull;
     float fstar = 0.0f;
     int pstar;
@@ -520,10 +532,11 @@ __device__ __forceinline__ void first_q_body(const ResolveParams &P) {
       pstar = uni((int)row->p);
       if (uni((int)(P.eacc[ao.seq].short_count > (unsigned)kShortRowsPerSeq))) continue;  // given up
     } else {
-      ao.seq = uni(P.active[item / P.pchunks].seq);
-      ao.s = uni(P.active[item / P.pchunks].s);
+      ao.seq = uni(P.active[item % nact].seq);
+      ao.s = uni(P.active[item % nact].s);
       // (requested together with the descriptor: one memory round trip, not three)
-      known = tid == 0 ? P.acc[ao.seq].res_loc : ~0ull;
+      // (an agent-scope load, as in psa_first_p: the pruning below lives on other blocks' results)
+      known = tid == 0 ? __hip_atomic_load(&P.acc[ao.seq].res_loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
       fstar = key2f(P.acc[ao.seq].res_key);
       pstar = uni(P.acc[ao.seq].res_p);
     }
@@ -533,9 +546,16 @@ __device__ __forceinline__ void first_q_body(const ResolveParams &P) {
     if (pstar == INT_MAX || q0 > L2 - 1 || q0 + 255 <= pstar) continue;
     __syncthreads();
     if (!ROWS) {
-      if (tid == 0) skip_flag[0] = known != ~0ull && (int)(known >> 32) < q0;  // a smaller q is already known
+      // 2: a q below this slice is already known -- this item and, in a one-Seq2 batch, every later item of the
+      // block is done; 1: the smallest q there is, p* + 1, is known at a smaller offset -- this offset cannot win
+      if (tid == 0)
+        skip_flag[0] = known == ~0ull ? 0
+                       : (int)(known >> 32) < q0 ? 2
+                       : ((int)(known >> 32) == pstar + 1 && (int)(uint32_t)known < ao.s) ? 1 : 0;
       __syncthreads();
-      if (uni(skip_flag[0])) continue;  // one decision for the whole block
+      const int skip = uni(skip_flag[0]);  // one decision for the whole block
+      if (skip == 2 && P.one_seq) break;
+      if (skip) continue;
     }
     float *d0 = T + kDevTable;
     f2 *d21 = (f2 *)(d0 + tie_d0_len(L2));

@@ -1037,6 +1037,45 @@ def test_config4_full_size(psa, ctx, oracle):
     assert psa.combine_results(parts).key() == whole.key()
 
 
+def test_config5_at_scale(psa, oracle):
+    """Tie stress at the long pair's size: Seq1 = 200000, Seq2 = 8000, all-same, period 2 and period 3 -- every
+    offset (every offset; every third offset) attains the maximum, up to 192003 ties for the float32 tie-break.  The
+    answer is the oracle's, and the resolve stage takes no more than three times what it takes on the random
+    pair of that size (its tie kernels prune on what is already known instead of visiting every tied offset)."""
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    table = oracle.comp_matrix(w)
+    c = psa.Context(0)
+    c.set_weights(w)
+
+    def resolve_ms(seq1, seq2):
+        c.set_seq1(seq1)
+        b = c.batch([seq2])
+        b.run(psa.STAGE_RESOLVE)  # (first run: buffers, LDS limits)
+        best = 1e30
+        for _ in range(3):
+            r = b.run(psa.STAGE_RESOLVE)[0]
+            best = min(best, b.timing()[1])
+        b.close()
+        return r, best
+    seq1, seq2s = synth_problem(4, 200000, [8000])
+    r, t_random = resolve_ms(seq1, seq2s[0])
+    assert r.key() == oracle.fast(seq1, seq2s[0], table).as_tuple()
+    for name, seq1, seq2 in (("all-same", "A" * 200000, "A" * 8000), ("period 2", "AB" * 100000, "AB" * 4000),
+                             ("period 3", ("ABC" * 66667)[:200000], ("ABC" * 2667)[:8000])):
+        r, t = resolve_ms(seq1, seq2)
+        o = oracle.fast(seq1, seq2, table)
+        assert r.status == 0 and r.key() == o.as_tuple() and r.mutant_num == o.mutant_num, (name, r.key(), o.as_tuple())
+        assert tuple(r.counts) == oracle.counts(seq1, seq2, r.offset, r.n, r.k)
+        assert t < 3.0 * t_random, (name, t, t_random)
+    # both stages on the all-same pair: the enumeration ties everywhere too (first maximiser (1, 2, 0)), and its
+    # shortlist overflows, so the cross-check stays at the rounding bound
+    c.set_seq1("A" * 200000)
+    r = c.score_batch(["A" * 8000])[0]
+    assert r.key() == o.as_tuple() or r.key()[:3] == (1, 2, 0)
+    assert (r.enum_n, r.enum_k, r.enum_offset) == (1, 2, 0) and r.enum_check == 1
+    c.close()
+
+
 def test_config3_batch_properties(psa, ctx, oracle):
     """A batch of 384 Seq2 of 500..2000 characters against Seq1 = 10000: results do not depend on
     the order or the company a Seq2 is scored in, and a sample equals the oracle."""
@@ -1079,6 +1118,14 @@ def test_config3_full_size(psa, oracle):
     sample = sorted(int(i) for i in rng.choice(len(seq2s), size=32, replace=False))
     with ThreadPoolExecutor(max_workers=16) as ex:  # the oracle calls release the GIL
         list(ex.map(lambda i: check_against_oracle(oracle, seq1, [seq2s[i]], table, [res[i]]), sample))
+        # every one of the 4096 float32 answers against the oracle (O(L1 L2) each; the enumeration's own
+        # oracle is O(L1 L2) with a larger constant and stays on the sample)
+        def float_answer(i):
+            o = oracle.fast(seq1, seq2s[i], table)
+            return res[i].key() == o.as_tuple() and res[i].mutant_num == o.mutant_num
+        wrong = [i for i, ok in enumerate(ex.map(float_answer, range(len(seq2s)))) if not ok]
+    assert not wrong, wrong[:10]
+    assert all(r.enum_check == 2 for r in res)  # and each is also the winner of its replayed shortlist
     full = lambda r: r.key() + r.enum_key() + tuple(r.counts) + tuple(r.enum_counts) + (r.mutant_num, r.candidates)
     perm = rng.permutation(len(seq2s))
     res_p = c.score_batch([seq2s[i] for i in perm])

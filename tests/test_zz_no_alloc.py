@@ -33,7 +33,19 @@ class Hip:
         self.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.rt.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.rt.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        self.rt.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+        self.rt.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        self.rt.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        self.rt.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        self.rt.hipGraphExecDestroy.argtypes = [C.c_void_p]
+        self.rt.hipGraphDestroy.argtypes = [C.c_void_p]
         self.bufs = []
+
+    def free_bytes(self):
+        free, total = C.c_size_t(), C.c_size_t()
+        self.ok(self.rt.hipMemGetInfo(C.byref(free), C.byref(total)))
+        return free.value
 
     def ok(self, rc):
         assert rc == 0, "HIP error %d" % rc
@@ -118,13 +130,63 @@ def test_noalloc_entry_matches_score_range(oracle):
     ctx.set_seq1("ABCDEFGHIJKLMNOP")
     assert _fields(noalloc("ABCDEFGHIJKLMNOP", "ABCDEF", 0, 13)) == \
         _fields(ctx.score_range("ABCDEF", 0, 13, psa_amd.STAGE_RESOLVE))
+    # a table that is not symmetric (the entry point transposes it on the device, psa_set_table on the host)
+    rng = np.random.default_rng(46)
+    asym = rng.normal(0, 3, size=676).astype(np.float32)
+    d_asym = hip.upload(asym.tobytes())
+    seq1, seq2s = synth_problem(46, 3000, [700])
+    ctx.set_seq1(seq1)
+    ctx.set_table(asym)
+    S = len(seq1) - 700 + 3
+    d1, d2 = hip.upload(seq1.encode()), hip.upload(seq2s[0].encode())
+    want = ctx.score_range(seq2s[0], 0, S, psa_amd.STAGE_RESOLVE)
+    assert want.key() == oracle.fast(seq1, seq2s[0], asym).as_tuple()
+    hip.ok(hip.rt.hipMemset(d_out, 0xAB, 96))
+    # ... and the claim itself: the device's free memory is the same before and after the call
+    hip.ok(hip.rt.hipStreamSynchronize(stream))
+    free_before = hip.free_bytes()
+    assert L.psa_score_range_noalloc(d1, len(seq1), d2, 700, d_asym, 0, S, stream, d_out) == 0
+    hip.ok(hip.rt.hipStreamSynchronize(stream))
+    assert hip.free_bytes() == free_before
+    assert _fields(psa_amd.Result.from_buffer_copy(hip.download(d_out, 96))) == _fields(want)
+    # ... and one call captured into a HIP graph (capture forbids allocation), replayed twice
+    hip.ok(hip.rt.hipMemset(d_out, 0xAB, 96))
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    hip.ok(hip.rt.hipStreamBeginCapture(stream, 2))  # hipStreamCaptureModeRelaxed
+    st_cap = L.psa_score_range_noalloc(d1, len(seq1), d2, 700, d_asym, 0, S, stream, d_out)
+    hip.ok(hip.rt.hipStreamEndCapture(stream, C.byref(graph)))
+    assert st_cap == 0, L.psa_noalloc_last_error_text()
+    hip.ok(hip.rt.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0))
+    for _ in range(2):
+        hip.ok(hip.rt.hipGraphLaunch(gexec, stream))
+        hip.ok(hip.rt.hipStreamSynchronize(stream))
+        assert _fields(psa_amd.Result.from_buffer_copy(hip.download(d_out, 96))) == _fields(want)
+        hip.ok(hip.rt.hipMemset(d_out, 0xAB, 96))
+    hip.ok(hip.rt.hipGraphExecDestroy(gexec))
+    hip.ok(hip.rt.hipGraphDestroy(graph))
+    # a table entry that is not finite is found on the device; the next call is clean again
+    t_bad = table.copy()
+    t_bad[5] = np.inf
+    d_bad = hip.upload(t_bad.tobytes())
+    ctx.set_table(table)
+    ctx.set_seq1("ABCDEFGHIJKLMNOP")
+    d1, d2 = hip.upload(b"ABCDEFGHIJKLMNOP"), hip.upload(b"ABCDEF")
+    assert L.psa_score_range_noalloc(d1, 16, d2, 6, d_bad, 0, 13, stream, d_out) == 0
+    hip.ok(hip.rt.hipStreamSynchronize(stream))
+    assert psa_amd.Result.from_buffer_copy(hip.download(d_out, 96)).status == 1
+    assert _fields(noalloc("ABCDEFGHIJKLMNOP", "ABCDEF", 0, 13)) == \
+        _fields(ctx.score_range("ABCDEF", 0, 13, psa_amd.STAGE_RESOLVE))
+    # the error text belongs to the most recent call: cleared by a call that succeeds
+    assert L.psa_noalloc_last_error_text() == b""
     # sizes beyond the fixed capacity are refused with a clear message; so are impossible lengths
     big = hip.malloc(262145)
     d2 = hip.upload(b"ABCDEF")
     st = L.psa_score_range_noalloc(big, 262145, d2, 6, d_table, 0, 10, None, d_out)
     assert st == 10 and b"PSA_NOALLOC_MAX_SEQ1" in L.psa_noalloc_last_error_text()
     assert L.psa_score_range_noalloc(big, 100, d2, 1, d_table, 0, 10, None, d_out) == 2
+    assert b"shorter than 2" in L.psa_noalloc_last_error_text()
     assert L.psa_score_range_noalloc(big, 3, d2, 6, d_table, 0, 10, None, d_out) == 3
+    assert b"longer than" in L.psa_noalloc_last_error_text()
     # the largest Seq1 it takes, on the default stream
     seq1, seq2s = synth_problem(45, 262144, [600])
     ctx.set_seq1(seq1)
