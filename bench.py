@@ -74,6 +74,10 @@ SIMDS = 256 * 4
 PEAK_CLOCK_HZ = 2.4e9
 CYCLES_PER_TILE_BOUND = 32.0
 BARE_LOOP_CYCLES_PER_TILE = {"4 waves per SIMD": 39.5, "8 waves per SIMD": 37.4}
+# What this instruction mix can reach at best: a matrix instruction holds the SIMD's vector issue for 8 of its
+# 32 cycles, issue costs add, "and an MFMA gap runs about max(32, their sum)" (MI355X_MICROARCH.md,
+# per-instruction cycle constants, row 'vector-instruction ISSUE cost'): 8 v_max3_f32 x 4 + 8 = 40.
+ISSUE_FLOOR_CYCLES_PER_TILE = 40.0
 PEAK_CANDIDATES = SIMDS * PEAK_CLOCK_HZ * 1024.0 / CYCLES_PER_TILE_BOUND  # 7.86e13 candidates/s
 
 
@@ -213,20 +217,19 @@ def cpu_baseline(seq1, seq2, budget_s=12.0):
 
 
 def measured_traffic(cfg):
-    """Memory-side bytes per launch of the candidate-loop kernel as the TCC counters saw them in the
-    committed rocprofv3 run of this workload (profiles/r02_c2_pmc.json); None for workloads not
-    profiled.  The kernel reads its rows with one dword per lane, which FETCH_SIZE counts at half
-    (calibration: profiles/r01_fetch_size_calibration.txt), so traffic = 2 x FETCH_SIZE + WRITE_SIZE."""
-    if cfg != "c2":
-        return None, None
-    path = os.path.join(ROOT, "profiles", "r02_c2_pmc.json")
-    if not os.path.exists(path):
-        return None, None
-    with open(path) as f:
-        kernels = json.load(f)["kernels"]
-    for kname, c in kernels.items():
-        if "psa_enum_wave_mfma<false>" in kname and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "profiles/r02_c2_pmc.json"
+    """Memory-side bytes per LAUNCH of the candidate-loop kernel as the TCC counters saw them in the committed
+    rocprofv3 --pmc passes of this workload (profiles/r03_<cfg>_pmc.json, else round 2's file); None for
+    workloads not profiled.  The kernel reads its rows with one dword per lane, which FETCH_SIZE counts at
+    half (calibration: profiles/r01_fetch_size_calibration.txt), so traffic = 2 x FETCH_SIZE + WRITE_SIZE."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, cfg))
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        for kname, c in kernels.items():
+            if "psa_enum_wave_mfma<false>" in kname and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "profiles/%s_%s_pmc.json" % (rnd, cfg)
     return None, None
 
 
@@ -295,12 +298,18 @@ class Job:
                 return None
         return self._data_group
 
+    def collective_label(self):
+        """What carried the long pair's exchanges: "rccl", "gloo" (rehearsal, or RCCL could not be created) or none."""
+        if self._data_group is not None:
+            return "rccl"
+        return "gloo" if self.dist is not None else "none (one rank, no process group)"
+
     def allgather_bytes(self):
         from psa_amd import dist as pdist
         return pdist.allgather_bytes(self.data_group()) if self.dist is not None else None
 
 
-def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_steps):
+def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_steps, repeats=0, host_pass=False):
     """Runs one workload; returns a dict with the timing, the records and the parity verdict."""
     import psa_amd
     from psa_amd import dist as pdist
@@ -382,6 +391,18 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
     job.barrier()
     elapsed = time.perf_counter() - t0
 
+    # The same timed region again, `repeats` times (reported beside the first, never instead of it): a region
+    # of a few milliseconds says little about the box's run-to-run spread by itself.
+    region_ms = []
+    for _ in range(repeats if pipelined else 0):
+        job.barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            batch.enqueue(stages)
+        batch.wait()
+        job.barrier()
+        region_ms.append(1e3 * (time.perf_counter() - t1) / steps)
+
     # Duration of the candidate-loop kernel on its own.  In a pipelined timed region two of its
     # launches (consecutive steps) share the GPU, so the dispatch events of one launch span more
     # than its own work; here every step is awaited before the next is launched (its own
@@ -407,6 +428,30 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
         clock_mhz, _ = ctx.clock_probe(False)
 
     res = batch.results()
+    npasses = batch.passes()
+    # c3 through the calls a host program makes: the rank's share from host buffers, in sub-batches that are
+    # created (work lists built and uploaded), enqueued and waited for three deep -- against the resident step
+    host_pass_ms = None
+    if host_pass and cfg == "c3":
+        job.barrier()
+        t1 = time.perf_counter()
+        sub, inflight, got = 256, [], []
+        for i0 in range(0, len(my_seq2), sub):
+            bb = ctx.batch(my_seq2[i0:i0 + sub])
+            bb.enqueue(stages)
+            inflight.append(bb)
+            if len(inflight) == 3:
+                b0 = inflight.pop(0)
+                b0.wait()
+                got += b0.results()
+                b0.close()
+        for b0 in inflight:
+            b0.wait()
+            got += b0.results()
+            b0.close()
+        host_pass_ms = 1e3 * (time.perf_counter() - t1)
+        if [bytes(a) for a in got] != [bytes(a) for a in res]:
+            raise SystemExit("c3 from host buffers in sub-batches: records differ from the resident batch's")
     bad_status = [r.status for r in res if r.status != 0]
     if bad_status:
         raise SystemExit("workload has invalid Seq2: %r" % bad_status)
@@ -476,6 +521,7 @@ def run_workload(job, ctx, args, cfg, steps, warmup, prewarm_s, nseq2, sync_step
         "parity_checked": checked, "enum_ms": enum_ms, "gpu_ms": gpu_ms, "iso_enum_ms": iso_enum_ms,
         "iso_gpu_ms": iso_gpu_ms, "n_iso": n_iso, "pipelined": pipelined, "stages": stages, "clock_mhz": clock_mhz,
         "seq1": seq1, "seq2s": seq2s, "my_seq2": my_seq2, "res": res, "shard": shard,
+        "npasses": npasses, "region_ms": region_ms, "host_pass_ms": job.gather_objects(host_pass_ms),
     }
     return out
 
@@ -498,6 +544,7 @@ def roofline_block(cfg, w):
         offsets = [float(w["shard"][1] - w["shard"][0])]
     slab_bytes = sum(4.0 * len(s2) * n for s2, n in zip(w["my_seq2"], offsets))
     traffic, traffic_src = measured_traffic(cfg) if mfma_loop() else (None, None)
+    launches = max(1, w.get("npasses") or 1)  # candidate-loop launches per step (slab passes)
     my_elapsed = w["per_rank"][0][0]
     lane_op_frac = cand_rank * OPS_PER_CANDIDATE / kern_s / PEAK_INT32_LANE_OPS
     mfma = mfma_loop()
@@ -505,8 +552,12 @@ def roofline_block(cfg, w):
         "traffic": traffic,
         "traffic_unit": "bytes per launch from the committed rocprofv3 --pmc passes of this command (%s: 2 x FETCH_SIZE, "
                         "which counts the kernel's dword-per-lane reads at half, + WRITE_SIZE; reads served by the "
-                        "Infinity Cache included); a constant read from that file, not measured by this run"
+                        "Infinity Cache included), mean per launch of the kernel; a constant read from that file, not "
+                        "measured by this run"
                         % traffic_src if traffic is not None else None,
+        # measured bytes against the rows one launch covers (a step's rows / its launches): above 1 = re-reads
+        "traffic_ratio": traffic / (slab_bytes / launches) if traffic is not None else None,
+        "launches_per_step": launches,
         "kernel_ms": kern_s * 1e3,
         # the same launch inside the timed region, where it shares the GPU with the launch
         # of the step before or after it (null when steps are awaited one by one: no sharing)
@@ -549,6 +600,10 @@ def roofline_block(cfg, w):
         "bound_cycles_per_tile": CYCLES_PER_TILE_BOUND,
         "bare_loop_cycles_per_tile": BARE_LOOP_CYCLES_PER_TILE,
         "cycles_per_tile_measured": cyc_per_tile,
+        # the floor of this instruction mix by the guide's issue-cost rule (8 maxima x 4 cycles + the matrix
+        # instruction's 8): the 32-cycle bound above is the ceiling to quote, this is what the loop can reach
+        "issue_floor_cycles_per_tile": ISSUE_FLOOR_CYCLES_PER_TILE,
+        "frac_of_issue_floor": ISSUE_FLOOR_CYCLES_PER_TILE / cyc_per_tile if cyc_per_tile else None,
         # tiles against the 32-cycle bound at the clock the kernel really ran at (<= 1 by construction):
         # the share of the time the matrix cores are busy, and equally the share the maxima alone need of the port
         "matrix_core_busy_frac": CYCLES_PER_TILE_BOUND / cyc_per_tile if cyc_per_tile else None,
@@ -593,6 +648,60 @@ def host_inclusive(ctx, seq1, seq2s, calls=20):
     return out
 
 
+def boundary_block(seq1, seq2s, records, calls=10):
+    """The workload through the drop-in boundary with the candidate loop ON (P/cudaFunctions.cu:290-296: every
+    call of the reference through the boundary runs its per-candidate kernel): psa_calc_best_score -- what the
+    reference's main.c calls once per Seq2, P/main.c:81, :130 -- under PSA_STAGES=enumerate and =both, and the
+    host program psa_host on a generated input.txt of this workload (process start, HIP start-up, file I/O and
+    all).  The returned lines are compared with the records the parity gate has checked.  Never the headline."""
+    import subprocess
+    import tempfile
+    import psa_amd
+    os.environ["PSA_SHIM_QUIET"] = "1"
+    table = psa_amd.createCompMatrix(WEIGHTS)
+    want = [psa_amd.format_result(r) for r in records]
+    cand = sum((len(seq1) - len(s) + 3) * (len(s) * (len(s) - 1) // 2) for s in seq2s)
+    out = {"workload_candidates": cand, "lines_equal_parity_checked_records": True}
+    for mode in ("resolve", "enumerate", "both"):
+        os.environ["PSA_STAGES"] = mode
+        lines = [psa_amd.calc_best_score(seq1, s, table) for s in seq2s]  # (first calls: buffers)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            for s in seq2s:
+                psa_amd.calc_best_score(seq1, s, table)
+        ms = 1e3 * (time.perf_counter() - t0) / (calls * len(seq2s))
+        out["psa_calc_best_score_PSA_STAGES=" + mode] = {
+            "ms_per_seq2": ms, "candidates_per_s": (cand / len(seq2s)) / ms * 1e3 if mode != "resolve" else None}
+        if lines != want:
+            out["lines_equal_parity_checked_records"] = False
+    os.environ.pop("PSA_STAGES", None)
+    exe = os.path.join(ROOT, "parallel-sequence-alignment_amd", "psa_host")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as tmp:
+            inp, outp = os.path.join(tmp, "input.txt"), os.path.join(tmp, "output.txt")
+            with open(inp, "w") as f:
+                f.write("%s\n%s\n%d\n%s\n" % (" ".join("%g" % x for x in WEIGHTS), seq1, len(seq2s), "\n".join(seq2s)))
+            for mode in ("resolve", "enumerate"):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "--stages=" + mode, inp, outp, "1"], capture_output=True, text=True, timeout=300)
+                wall = time.perf_counter() - t0
+                own = [l for l in r.stdout.splitlines() if l.startswith("Total Time: ")]
+                ok = r.returncode == 0 and open(outp).read().splitlines(keepends=True) == want
+                out["psa_host --stages=" + mode] = {
+                    "wall_s": wall, "program_total_time_s": float(own[0].split()[-1]) if own else None,
+                    "candidates_per_s_of_wall": cand / wall if mode == "enumerate" else None, "output_txt_equal": ok}
+                if not ok:
+                    out["psa_host --stages=" + mode]["failure"] = (r.returncode, r.stdout[-300:], r.stderr[-300:])
+                    # a child killed by a signal before it wrote anything says nothing about the records;
+                    # lines that differ do
+                    if r.returncode >= 0:
+                        out["lines_equal_parity_checked_records"] = False
+    out["note"] = ("psa_calc_best_score = one Seq2 per call, host strings in, formatted line out (batch built, uploaded, "
+                   "scored and released per call); psa_host = a fresh process per run: its wall time is dominated by "
+                   "process and HIP start-up, program_total_time_s is what the program itself prints (P/main.c:97)")
+    return out
+
+
 def shortlist_stats(records):
     """How the records' answers are tied to the enumerated candidates: enum_check 2 = the float32 replay of the
     shortlisted candidates (those within the rounding window of the enumerated maximum) returned this very record,
@@ -613,6 +722,9 @@ def scale_entry(w, world):
             "per_rank_ms_per_step": [1e3 * p[0] / w["steps"] for p in w["per_rank"]],
             "imbalance_max_over_mean": max(p[0] for p in w["per_rank"]) / (sum(p[0] for p in w["per_rank"]) / world),
             "parity": w["parity"], "parity_checked_records": w["parity_checked"],
+            # the same list from host buffers: sub-batches of 256 Seq2 created, enqueued and awaited three deep
+            # (work lists built and uploaded per sub-batch), each rank its share; ms for the whole share, once
+            "host_inclusive_ms_per_rank": w["host_pass_ms"] if any(x is not None for x in w["host_pass_ms"]) else None,
             "shortlist": shortlist_stats(w["answer"]) if w["stages"] == 3 else None,
             "result_sample": {"n": w["answer"][0].n, "k": w["answer"][0].k, "offset": w["answer"][0].offset,
                               "score_bits": "0x%08x" % w["answer"][0].score_bits} if w["answer"] else None}
@@ -637,6 +749,10 @@ def main():
     ap.add_argument("--no-scale", action="store_true", help="skip the scale block (c3 and c4) of the default run")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="wait for every step before launching the next")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="how often the timed region is run again after the reported one (c1/c2; median, min and max "
+                         "of ms per step go into timing_repeats)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary block (drop-in shim and psa_host with the candidate loop on)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group even for one rank (under torch.distributed.run): runs the "
                          "broadcast, gathers and the long pair's all-gather through the backend on a one-GPU box")
@@ -651,18 +767,19 @@ def main():
     rank, world = job.rank, job.world
     import psa_amd
     ctx = psa_amd.Context(job.local_rank)
-    w = run_workload(job, ctx, args, args.config, args.steps, args.warmup, args.prewarm_s, args.nseq2, args.sync_steps)
+    w = run_workload(job, ctx, args, args.config, args.steps, args.warmup, args.prewarm_s, args.nseq2, args.sync_steps,
+                     repeats=args.repeats, host_pass=args.config == "c3" and not args.no_host_inclusive)
 
     scale = None
     if args.config == "c2" and not args.no_scale:
         # strong scaling of the two sharded workloads on the same ranks: few steps, full sizes
         scale = {}
         for cfg, steps in (("c3", 2), ("c4", 3)):
-            ws = run_workload(job, ctx, args, cfg, steps, 1, 0.0, 4096, False)
+            ws = run_workload(job, ctx, args, cfg, steps, 1, 0.0, args.nseq2, False,
+                              host_pass=cfg == "c3" and not args.no_host_inclusive)
             scale[cfg] = scale_entry(ws, world)
             scale[cfg]["complaints"] = ws["complaints"][:5]
-        scale["c4"]["collective"] = ("rccl" if job._data_group is not None else
-                                     "gloo" if job.dist is not None else "none (one rank, no process group)")
+        scale["c4"]["collective"] = job.collective_label()
         scale["note"] = ("c3 = BASELINE's list of 4096 Seq2 divided among the ranks by psa_partition (no data-path "
                          "collective, records gathered to rank 0 and compared with a one-rank run); c4 = one pair, "
                          "offsets sharded, one all-gather of a 96-byte record per rank and the max-loc combine "
@@ -689,6 +806,9 @@ def main():
                               "complaints": w["complaints"][:5],
                               "shortlist": shortlist_stats(w["answer"]) if w["stages"] == 3 else None},
             "config": {"workload": w["name"], "stages": args.stages, "weights": [float(x) for x in WEIGHTS],
+                       "collective": job.collective_label() if args.config == "c4" else None,
+                       "exchanges_per_step": ((2 if w["stages"] & 1 else 1) if world > 1 or job.dist is not None else 0)
+                       if args.config == "c4" else None,
                        "candidates_per_step": w["cand_total"], "prewarm_s": args.prewarm_s,
                        "per_rank_ms_per_step": [1e3 * p[0] / w["steps"] for p in w["per_rank"]]},
             "result_sample": {"n": res0.n, "k": res0.k, "offset": res0.offset,
@@ -699,8 +819,22 @@ def main():
             out["roofline"] = roofline_block(args.config, w)
         if scale is not None:
             out["scale"] = scale
+        if w["region_ms"]:
+            rm = sorted(w["region_ms"])
+            out["timing_repeats"] = {"regions": len(rm), "steps_per_region": w["steps"],
+                                     "ms_per_step_median": rm[len(rm) // 2], "ms_per_step_min": rm[0], "ms_per_step_max": rm[-1],
+                                     "note": "the timed region run again after the reported one; value and ms_per_step "
+                                             "above are the first region's"}
         if not args.no_host_inclusive and args.config in ("c1", "c2"):
             out["host_inclusive"] = host_inclusive(ctx, w["seq1"], w["my_seq2"])
+        if not args.no_boundary and args.config in ("c1", "c2") and w["parity"]:
+            out["boundary"] = boundary_block(w["seq1"], w["my_seq2"], w["res"])
+            parity = parity and out["boundary"]["lines_equal_parity_checked_records"]
+            out["parity"] = parity
+        if args.config == "c3" and any(x is not None for x in w["host_pass_ms"]):
+            out["host_inclusive"] = {"ms_per_rank_whole_share": w["host_pass_ms"],
+                                     "note": "the rank's share from host buffers in sub-batches of 256 Seq2, created, "
+                                             "enqueued and awaited three deep; compare with ms_per_step (resident)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w["seq1"], w["my_seq2"][0])
         print(json.dumps(out))

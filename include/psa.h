@@ -88,8 +88,10 @@ typedef struct psa_result {
  *
  * The shortlist.  The candidate the reference reports has a fixed-point score within 2b of the enumerated
  * maximum, so an enumerating run lists every row (offset, n) that holds a candidate inside that window, with
- * the 256-wide blocks of k that hold one (per Seq2 up to 1024 rows and 256 listed n per offset, per run up
- * to 2^20 rows), and replays the listed blocks in float32 exactly as calcMutantScore adds a candidate
+ * the 256-wide blocks of k that hold one (per Seq2 up to 1024 rows and 256 listed n per offset; the run's
+ * list has room for every Seq2's full quota, so whether a Seq2's list overflows depends on that Seq2 alone --
+ * in a batch of more than 16384 Seq2 the quota is 2^24 rows divided by their number), and replays the listed
+ * blocks in float32 exactly as calcMutantScore adds a candidate
  * (P/cudaFunctions.cu:210-220); the replayed winner -- highest score, ties to the smallest (n, k, offset) --
  * is then the reference's answer, obtained from the enumerated candidates alone.
  *   - Run with both stages: enum_check = 2 when that winner equals the resolve stage's record bit for bit
@@ -154,6 +156,8 @@ int psa_batch_run(psa_batch *b, uint32_t stages);
  * order, so a caller that streams many batches keeps the GPU busy while it prepares the next
  * one -- the per-Seq2 blocking call of the reference (P/main.c:81, :130) has no such overlap.
  * A batch holds one set of records: enqueueing it again before wait overwrites them.
+ * Enqueue returns at once unless the context already has some 500 slab passes (a few thousand kernel
+ * launches: a list of thousands of Seq2) enqueued and unfinished; then it first waits for the oldest.
  * Wait for results with psa_batch_wait (the host waits for an event), not by making a stream of
  * your own wait on the library's work: the library's streams all have the default priority, and
  * a wait in a higher-priority queue on a dispatch that sits in a lower-priority queue is never
@@ -171,6 +175,9 @@ int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms)
  * NULL.  No counterpart in the reference. */
 int psa_batch_shortlist(const psa_batch *b, int32_t *count, int32_t *state);
 int psa_batch_size(const psa_batch *b);
+/* candidate-loop launches of one enumerating run of this batch: its rows of g are cut into passes that
+ * fit one slab (256 MiB) each.  Measurement aid, no counterpart in the reference. */
+int psa_batch_passes(const psa_batch *b);
 void psa_batch_destroy(psa_batch *b);
 
 /* create + run + results + destroy */
@@ -223,7 +230,7 @@ typedef int (*psa_allgather_fn)(const void *send, void *recv, size_t bytes, void
  *     best replayed winner of all shards equals the combined float32 answer bit for bit (-2 if it does
  *     not), 1 when some shard's list overflowed.
  * Every rank of the communicator must call it, with the same stages; with nranks == 1 the callback may
- * be NULL.  A rank whose scoring fails, or whose context is not ready, still takes part in every
+ * be NULL (no exchange; if one is given, the run goes through it as a one-rank all-gather).  A rank whose scoring fails, or whose context is not ready, still takes part in every
  * all-gather of the run and all ranks return that status.  A run of PSA_STAGE_ENUMERATE alone returns the
  * float32 fields of the best replayed winner, or zeros if some shard's list overflowed. */
 int psa_score_range_allgather(psa_ctx *ctx, const char *seq2, int32_t len2, int rank, int nranks,

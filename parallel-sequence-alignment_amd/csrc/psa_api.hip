@@ -89,6 +89,16 @@ struct psa_ctx {
   size_t slab_units = 0;  // capacity of each slab in runs of 64 int32
   int slab_count = 0;
   hipEvent_t ev_prep[kMaxSlabs] = {};
+  // Bound on the work in flight: every kFencePasses-th slab pass records a fence behind its candidate loop, and
+  // before a fence event is used again the host waits for its previous record, so at most kFences x
+  // kFencePasses passes (a few thousand launches) of the context are ever enqueued and not yet finished.
+  // Without it a caller that enqueues two runs of a 4096-Seq2 list back to back has some six thousand
+  // launches and their completion signals outstanding -- measured on ROCm 7.2: from then on, and until that
+  // process ends, every OTHER process that initialises HIP on the machine dies in the runtime's event thread.
+  static constexpr int kFences = 8, kFencePasses = 64;
+  hipEvent_t fence[kFences] = {};
+  bool fence_used[kFences] = {};
+  int fence_at = 0, passes_since_fence = 0;
   hipEvent_t slab_reader[kMaxSlabs] = {};  // end of the last candidate loop that read slab i (a batch's event)
   psa_batch *slab_reader_batch[kMaxSlabs] = {};
   int slab_flip = 0;
@@ -148,6 +158,7 @@ struct psa_batch {
   // accumulators; what the record kernel reports of them lands beside the records
   psa::ShortRow *d_short = nullptr;
   int short_cap = 0;  // rows of one copy of the list
+  int short_quota = psa::kShortRowsPerSeq;  // rows one Seq2 may list
   psa::ShortOut *h_short = nullptr, *d_short_out = nullptr;
   bool pending_short = false;  // the enqueued run fills h_short
   // start of the first / end of the last kernel on the enumeration side and on the resolve side
@@ -235,6 +246,7 @@ int psa_init(int device, psa_ctx **out) {
   if (const char *e = std::getenv("PSA_ENUM_STREAMS")) c->enum_streams = std::atoi(e) == 1 ? 1 : 2;  // tuning aid
   if (const char *e = std::getenv("PSA_SLABS")) c->nslabs = std::atoi(e) == 2 ? 2 : kMaxSlabs;          // tuning aid
   for (hipEvent_t &e : c->ev_prep) PSA_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t &e : c->fence) PSA_HIP_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PSA_HIP_C(hipMalloc((void **)&c->d_table_t, psa::kDevTable * sizeof(float)));
   PSA_HIP_C(hipMalloc((void **)&c->d_class_t, psa::kDevTable));
   PSA_HIP_C(hipMalloc((void **)&c->d_probe, 64 * 8 * sizeof(unsigned long long)));
@@ -275,6 +287,8 @@ void psa_shutdown(psa_ctx *c) {
     if (p) (void)hipFree(p);
   for (Bundle *u : c->spare) bundle_free(u);
   for (hipEvent_t e : c->ev_prep)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->fence)
     if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -655,15 +669,17 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
   const size_t o_cnt = align_up(o_acc + 2 * (size_t)n * sizeof(psa::SeqAcc), 256);
   const size_t o_fs = align_up(o_cnt + 64, 256);
   const size_t o_active = align_up(o_fs + (size_t)fs_total * sizeof(float), 256);
-  // The shortlist of a run: room for every Seq2's full quota of rows up to a million rows (24 MB), so that
-  // below that a record does not depend on what else its batch holds (a list split over ranks returns the
-  // records of the whole list); beyond it a batch of mostly low-entropy Seq2 can fill the list, and the Seq2
-  // that find it full are given up like those over their own quota.
-  int short_cap = 0;
+  // The shortlist of a run has room for every Seq2's full quota of rows, so that a record depends on nothing
+  // but its own Seq2 (a list split over ranks returns the records of the whole list, run after run).  The
+  // quota is kShortRowsPerSeq unless the list would pass kShortBudgetRows (more than 16384 Seq2 in one batch).
+  int short_cap = 0, short_quota = psa::kShortRowsPerSeq;
   if (c->shortlist && !chunks.empty()) {
-    short_cap = (int)std::min<int64_t>((int64_t)std::max(1, b->nvalid) * psa::kShortRowsPerSeq, 1 << 20);
-    if (const char *e = std::getenv("PSA_SHORT_ROWS")) short_cap = std::max(1, std::min(1 << 20, std::atoi(e)));  // test aid
+    if (const char *e = std::getenv("PSA_SHORT_ROWS")) short_quota = std::max(1, std::min(psa::kShortRowsPerSeq, std::atoi(e)));  // test aid
+    const int64_t nv = std::max(1, b->nvalid);
+    if (nv * short_quota > psa::kShortBudgetRows) short_quota = (int)std::max<int64_t>(1, psa::kShortBudgetRows / nv);
+    short_cap = (int)(nv * short_quota);
   }
+  b->short_quota = short_quota;
   b->short_cap = short_cap;
   const size_t o_short = align_up(o_active + (size_t)fs_total * sizeof(psa::ActiveOffset), 256);
   const size_t dev_bytes = align_up(o_short + 2 * (size_t)short_cap * sizeof(psa::ShortRow), 256) + 256;
@@ -773,6 +789,8 @@ int psa_batch_create_range(psa_ctx *c, const char *seq2, int32_t len2, int64_t s
 
 int psa_batch_size(const psa_batch *b) { return b ? b->n : 0; }
 
+int psa_batch_passes(const psa_batch *b) { return b ? (int)b->passes.size() : 0; }
+
 // Enqueues one run on the streams of the context: pre-passes on st_pre; candidate loops
 // alternating between the two st_enum, the last one followed on its stream by locate and the
 // enumeration half of the records; the resolve chain with its half of the records on st_res.
@@ -838,6 +856,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
     P.short_rows = b->d_short ? b->d_short + (size_t)par * (size_t)b->short_cap : nullptr;
     P.short_total = b->d_short ? b->d_counters + 1 + par : nullptr;
     P.short_rows_cap = b->short_cap;
+    P.short_quota = b->short_quota;
+    F.short_quota = b->short_quota;
     P.has_short_ref = short_ref ? 1 : 0;
     P.short_ref = short_ref ? *short_ref : 0;
     F.short_total = P.short_total;
@@ -901,6 +921,14 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       int wpg = b->cap_loops ? 8 : 1;
       if (const char *e = std::getenv("PSA_ENUM_WPG")) wpg = std::max(1, std::min(8, std::atoi(e)));  // tuning aid
       PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, mfma_loop, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
+      if (++c->passes_since_fence >= psa_ctx::kFencePasses) {
+        const int slot = c->fence_at;
+        if (c->fence_used[slot]) PSA_HIP(hipEventSynchronize(c->fence[slot]));  // the host runs too far ahead
+        PSA_HIP(hipEventRecord(c->fence[slot], st_loop));
+        c->fence_used[slot] = true;
+        c->fence_at = (slot + 1) % psa_ctx::kFences;
+        c->passes_since_fence = 0;
+      }
       sp.last_buf = buf;
       c->slab_reader[buf] = sp.ev_e[buf];
       c->slab_reader_batch[buf] = b;
@@ -944,6 +972,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       R.short_rows = P.short_rows;
       R.short_total = P.short_total;
       R.short_rows_cap = P.short_rows_cap;
+      R.short_quota = P.short_quota;
       R.eacc = eacc;
       PSA_HIP(psa::launch_short_replay(R, b->max_len2, std::max(256, std::min(4096, b->nvalid * R.pchunks * 8)), st_tail));
     }
@@ -1292,7 +1321,9 @@ int run_shard_allgather(psa_batch *b, int st0, int nranks, psa_allgather_fn allg
     g_err = "psa_batch_run_allgather: the batch must hold exactly one Seq2 (one shard of one pair)";
     st = PSA_ERR_ARG;
   }
-  const bool two_parts = nranks > 1 && (stages & PSA_STAGE_ENUMERATE);
+  // (one rank with a callback runs the same protocol over a one-rank all-gather: a rehearsal of the transport)
+  const bool exchange = nranks > 1 || allgather != nullptr;
+  const bool two_parts = exchange && (stages & PSA_STAGE_ENUMERATE);
   if (!two_parts) {
     if (st == PSA_OK) st = psa_batch_run(b, stages);
   } else {
@@ -1355,7 +1386,7 @@ int run_shard_allgather(psa_batch *b, int st0, int nranks, psa_allgather_fn allg
     mine = ShardMsg{};
     mine.rec.status = st;
   }
-  if (nranks == 1) {  // what the combine returns for one part
+  if (!exchange) {  // what the combine returns for one part
     *out = mine.rec;
     return st != PSA_OK ? st : mine.rec.status;
   }

@@ -902,8 +902,9 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 //   one.  Per offset the block takes the maxima of f and of g (an offset whose two maxima do not
 //   add up to the window is done), lists the positions p that could reach the window with the
 //   best g behind them, and walks the row of g once per listed p.  A Seq2 with more rows than
-//   kShortRowsPerSeq is given up (its counter stays above that): on a low-entropy input every
-//   row can lie inside the window.
+//   the batch's quota is given up (its counter stays above that): on a low-entropy input every
+//   row can lie inside the window.  The list has room for every Seq2's full quota, so which Seq2
+//   are given up does not depend on the order in which blocks append their rows.
 template <int NT, int R>
 __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locate(EnumParams P) {
   using L = EnumLds<NT, R>;
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
   int *sg = bg + 128;                      // max of g over positions >= 64 i
   constexpr int NB = R * NW;
   static_assert(NB <= 128, "two values per lane in the suffix scan");
-  constexpr unsigned cap = (unsigned)kShortRowsPerSeq;
+  const unsigned cap = (unsigned)P.short_quota;
   // The next-but-one candidate loop waits on this kernel's stream while the next one fills every
   // SIMD with older waves: at the default priority this kernel's waves are issued last (steps of
   // 4 x Seq2 = 2000 enqueued back to back: 0.176 ms per step, 0.169 with the priority raised).
@@ -1061,7 +1062,7 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
               row.best = 0ull;
               P.short_rows[idx] = row;
             } else {
-              atomicMax(scount, cap + 1u);  // the run's list is full
+              atomicMax(scount, cap + 1u);  // (cannot happen: the list holds every Seq2's quota)
             }
           }
           // (the next offset's scan has barriers between these reads of the list and its reset)

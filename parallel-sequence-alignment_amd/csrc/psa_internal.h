@@ -38,7 +38,7 @@ struct SeqAcc {
   int32_t res_p;                // min p attaining the float32 maximum
   unsigned long long short_best;  // shortlist: max of (float32 score image << 32 | ~p << 16 | ~q) over the replayed rows
   uint32_t short_s;             // ... and the smallest offset among the rows that attain it
-  uint32_t short_count;         // rows appended for this Seq2 (beyond kShortRowsPerSeq: given up)
+  uint32_t short_count;         // rows appended for this Seq2 (beyond the batch's quota: given up)
 };
 
 // Shortlist of the enumeration stage.  The candidate the reference reports has a fixed-point score
@@ -46,8 +46,9 @@ struct SeqAcc {
 // fixed-point and the float32 left-to-right sum), so every (offset, p) that has such a candidate is
 // listed as a row, with the 256-wide blocks of q that hold one, and the listed blocks are replayed
 // in float32 exactly as P/cudaFunctions.cu:210-220 adds them.  One list per run for the whole
-// batch; a Seq2 with more than kShortRowsPerSeq rows is given up (a low-entropy input can put
-// every row inside the window), whatever else the batch holds.
+// batch, with room for every Seq2's full quota of rows: a Seq2 with more rows than the quota is given
+// up (a low-entropy input can put every row inside the window), and whether it is depends on nothing
+// but its own rows -- not on the other Seq2 of the batch, nor on the order in which blocks append.
 struct ShortRow {
   int32_t seq;
   int32_t s;
@@ -55,7 +56,8 @@ struct ShortRow {
   uint32_t qmask;           // bit c: some q in [256 c, 256 c + 256) lies inside the window
   unsigned long long best;  // replay: max over the row's q of (score image << 32 | ~q)
 };
-constexpr int kShortRowsPerSeq = 1024;
+constexpr int kShortRowsPerSeq = 1024;     // the quota, unless the batch is so large that ...
+constexpr int kShortBudgetRows = 1 << 24;  // ... its list would pass this many rows (24 bytes each, two copies): then budget / Seq2
 // What the record kernel reports of a Seq2's shortlist (pinned host memory, beside the records).
 struct ShortOut {
   uint32_t score_bits;  // the replayed winner: highest float32 score, ties to the smallest (n, k, offset)

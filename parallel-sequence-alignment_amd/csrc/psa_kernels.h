@@ -27,7 +27,8 @@ struct EnumParams {
   int *fg;                         // slab the pre-pass writes: per offset 64*nruns f values, then 64*nruns g values
   ShortRow *short_rows;            // locate: this run's shortlist (null: none), ...
   unsigned *short_total;           // ... rows appended so far ...
-  int short_rows_cap;              // ... and the list's capacity
+  int short_rows_cap;              // ... and the list's capacity: Seq2 of the batch x short_quota, so it never fills
+  int short_quota;                 // rows one Seq2 may list before it is given up
   // locate, one shard of a long pair: the shortlist window hangs below this fixed-point score (the maximum
   // over ALL shards, exchanged between the ranks after the candidate loops) instead of the shard's own
   int has_short_ref;
@@ -68,6 +69,7 @@ struct ResolveParams {
   ShortRow *short_rows;
   const unsigned *short_total;
   int short_rows_cap;
+  int short_quota;
   SeqAcc *eacc;          // the run's copy of the enumeration accumulators
 };
 
@@ -84,6 +86,7 @@ struct FinalParams {
   uint32_t which;   // PSA_STAGE_* bits: the halves of the records this launch fills
   unsigned *short_total;  // this run's shortlist row counter (null: no shortlist): reset by the enumeration half ...
   ShortOut *short_out;    // ... which reports the replayed winners here (pinned host memory)
+  int short_quota;        // rows one Seq2 may list before it is given up
   int short_empty_ok;     // a list without a row is complete (state 1, no winner): shards of a long pair, see EnumParams::short_ref
 };
 

@@ -530,7 +530,7 @@ __device__ __forceinline__ void first_q_body(const ResolveParams &P) {
       ao.seq = uni(row->seq);
       ao.s = uni(row->s);
       pstar = uni((int)row->p);
-      if (uni((int)(P.eacc[ao.seq].short_count > (unsigned)kShortRowsPerSeq))) continue;  // given up
+      if (uni((int)(P.eacc[ao.seq].short_count > (unsigned)P.short_quota))) continue;  // given up
     } else {
       ao.seq = uni(P.active[item % nact].seq);
       ao.s = uni(P.active[item % nact].s);
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void psa_short_pick(ResolveParams P) {
     const unsigned long long qmin = 0xffffffffu - (uint32_t)r.best;
     const unsigned long long k = (r.best & 0xffffffff00000000ull) | ((unsigned long long)(0xffffu - r.p) << 16) | (0xffffull - qmin);
     SeqAcc *a = P.eacc + r.seq;
-    if (a->short_count <= (unsigned)kShortRowsPerSeq && k == a->short_best) atomicMin(&a->short_s, (uint32_t)r.s);
+    if (a->short_count <= (unsigned)P.short_quota && k == a->short_best) atomicMin(&a->short_s, (uint32_t)r.s);
   }
 }
 
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
     if (P.short_out) {
       ShortOut *so = P.short_out + i;
       const bool listed = uni(enum_ok && P.short_total && d.enum_slack >= 0);
-      const bool within = uni(listed && ea.short_count <= (unsigned)kShortRowsPerSeq);
+      const bool within = uni(listed && ea.short_count <= (unsigned)P.short_quota);
       const bool complete = uni(within && ea.short_best != 0ull && ea.short_s != ~0u);
       if (within && !complete && P.short_empty_ok) {
         // one shard of a long pair, window hung below the maximum over all shards: this shard holds no
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
         so->score_bits = 0u;
         so->n = so->k = so->offset = 0;
         so->counts[0] = so->counts[1] = so->counts[2] = so->counts[3] = 0;
-        so->count = listed ? (int)min(ea.short_count, (unsigned)kShortRowsPerSeq) : 0;
+        so->count = listed ? (int)min(ea.short_count, (unsigned)P.short_quota) : 0;
         so->state = listed ? 2 : 0;
       }
     }

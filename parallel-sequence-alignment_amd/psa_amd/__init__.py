@@ -91,6 +91,7 @@ def lib():
     L.psa_batch_timing.argtypes = [vp, f32p, f32p]
     L.psa_batch_shortlist.argtypes = [vp, i32p, i32p]
     L.psa_batch_size.argtypes = [vp]
+    L.psa_batch_passes.argtypes = [vp]
     L.psa_batch_destroy.argtypes = [vp]
     L.psa_batch_destroy.restype = None
     L.psa_score_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), i32p, C.c_uint32, C.POINTER(Result)]
@@ -409,6 +410,10 @@ class Batch:
         cnt, st = (C.c_int32 * max(self.n, 1))(), (C.c_int32 * max(self.n, 1))()
         _check(lib().psa_batch_shortlist(self._h, cnt, st), "psa_batch_shortlist")
         return list(zip(cnt, st))[:self.n]
+
+    def passes(self):
+        """Candidate-loop launches of one enumerating run (slab passes)."""
+        return lib().psa_batch_passes(self._h)
 
     def timing(self):
         """(enumeration kernel ms, first launch to last completion ms) of the last run"""

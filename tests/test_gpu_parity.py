@@ -323,20 +323,30 @@ def test_shortlist_replay(psa, oracle, golden, monkeypatch):
         else:
             assert state == 2 and r.enum_check == 1 and o.n == 0 and o.score_bits == 0
     b.close()
-    # a run's list that is full (capacity forced down to 3 rows): the Seq2 that find it full are given up
-    monkeypatch.setenv("PSA_SHORT_ROWS", "3")
-    seq1b, seq2b = synth_problem(32, 1200, [300, 280, 250, 200])
+    # a small quota (3 rows per Seq2): the Seq2 with more rows are given up -- the same ones in every run and
+    # in whatever company they are scored (the list holds every Seq2's full quota, so nothing depends on the
+    # order in which blocks append)
+    seq1b, seq2b = synth_problem(32, 1200, [300, 280, 250, 200, 310, 270])
     c.set_seq1(seq1b)
+    full = c.batch(seq2b)
+    full.run()
+    rows = [cnt for cnt, _ in full.shortlist()]  # with the default quota: every list complete
+    assert all(state == 1 for _, state in full.shortlist()) and max(rows) > 3, rows
+    full.close()
+    monkeypatch.setenv("PSA_SHORT_ROWS", "3")
     b = c.batch(seq2b)
+    b1 = c.batch(seq2b[::-1][:4])
     monkeypatch.delenv("PSA_SHORT_ROWS")
     res = b.run()
     check_against_oracle(oracle, seq1b, seq2b, table, res)
     sl = b.shortlist()
-    assert any(state == 2 for _, state in sl) and all((r.enum_check == 2) == (state == 1) for r, (_, state) in zip(res, sl)), sl
-    again = b.run()  # the counters were left reset
-    assert [bytes(r) for r in again] == [bytes(r) for r in res] or b.shortlist() != sl  # (which Seq2 find the list full is a race)
-    check_against_oracle(oracle, seq1b, seq2b, table, again)
+    assert [state for _, state in sl] == [1 if n <= 3 else 2 for n in rows], (sl, rows)
+    assert all((r.enum_check == 2) == (state == 1) for r, (_, state) in zip(res, sl)), sl
+    for _ in range(3):  # the counters were left reset; the same records again
+        assert [bytes(r) for r in b.run()] == [bytes(r) for r in res] and b.shortlist() == sl
+    assert [bytes(r) for r in b1.run()] == [bytes(r) for r in res[::-1][:4]] and b1.shortlist() == sl[::-1][:4]
     b.close()
+    b1.close()
     c.close()
     # switched off
     monkeypatch.setenv("PSA_SHORTLIST", "0")
@@ -1137,6 +1147,54 @@ def test_config3_full_size(psa, oracle):
         got = c.score_batch([seq2s[i] for i in idx])
         assert all(full(g) == full(res[i]) for g, i in zip(got, idx))
     c.close()
+
+
+def _run_bench_ranks(nproc, bench_args, timeout=600):
+    """bench.py under torch.distributed.run in fresh child processes; returns the JSON line of rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py")] + bench_args
+    env = dict(os.environ)
+    env.pop("PSA_DEVICE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_share_one_gpu(psa):
+    """The multi-rank code of bench.py on a one-GPU box: two ranks (gloo, both on GPU 0) run the headline and the
+    scale block -- the list divided by psa_partition with the records gathered and compared with a one-rank run,
+    and the long pair with its two exchanges per step and the combine."""
+    d = _run_bench_ranks(2, ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "5", "--nseq2", "64",
+                             "--no-cpu-baseline", "--no-boundary", "--repeats", "2"])
+    assert d["parity"] is True and d["n_gpus"] == 2, d.get("parity_detail")
+    c3, c4 = d["scale"]["c3"], d["scale"]["c4"]
+    assert c3["parity"] and c3["n_ranks_seen"] == 2 and not c3["complaints"]
+    assert c4["parity"] and c4["n_ranks_seen"] == 2 and not c4["complaints"]
+    assert all(x > 0 for x in c3["per_rank_candidates"]) and all(x > 0 for x in c4["per_rank_candidates"])
+    assert c4["collective"] == "gloo"
+    # the answer of the long pair comes from the enumerated candidates at two ranks as on one
+    assert c4["shortlist"] == {"records": 1, "replay_equals_answer": 1, "bound_only": 0, "other": 0}
+    assert c3["shortlist"]["replay_equals_answer"] == c3["shortlist"]["records"] == 64
+
+
+def test_bench_one_rank_through_rccl(psa):
+    """The long pair's exchanges through an RCCL communicator (one rank: the only RCCL a one-GPU box can build):
+    process-group creation, the second group for the data path, device-side all-gather of the two messages."""
+    d = _run_bench_ranks(1, ["--gpus", "1", "--force-dist", "--backend", "nccl", "--config", "c4", "--steps", "2",
+                             "--no-cpu-baseline"])
+    assert d["parity"] is True, d.get("parity_detail")
+    assert d["config"]["collective"] == "rccl" and d["config"]["exchanges_per_step"] == 2
+    assert d["parity_detail"]["shortlist"]["replay_equals_answer"] == 1
 
 
 def test_authors_recorded_output(psa):
