@@ -858,6 +858,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
     P.short_rows_cap = b->short_cap;
     P.short_quota = b->short_quota;
     F.short_quota = b->short_quota;
+    P.prep_wave_form = b->cap_loops ? 0 : 1;  // (large batches: see psa_enum_prep_wave)
     P.has_short_ref = short_ref ? 1 : 0;
     P.short_ref = short_ref ? *short_ref : 0;
     F.short_total = P.short_total;
@@ -920,6 +921,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       // when a retiring workgroup frees two wave slots per SIMD at once.)
       int wpg = b->cap_loops ? 8 : 1;
       if (const char *e = std::getenv("PSA_ENUM_WPG")) wpg = std::max(1, std::min(8, std::atoi(e)));  // tuning aid
+      static const bool skip_loop = std::getenv("PSA_SKIP_LOOP") != nullptr;  // measurement aid: the pre-pass alone (records are void)
+      if (skip_loop) W.nunits = std::min(W.nunits, 1);
       PSA_HIP(psa::launch_enum_wave(c->d_slab[buf], W, c->enum_f32, mfma_loop, wpg, lds, st_loop, sp.ev_b[buf], sp.ev_e[buf]));
       if (++c->passes_since_fence >= psa_ctx::kFencePasses) {
         const int slot = c->fence_at;

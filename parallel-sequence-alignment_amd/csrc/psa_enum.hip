@@ -171,6 +171,107 @@ __global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
   }
 }
 
+// ---- pre-pass, one wave per chunk (Seq2 of at most 64 R positions, R <= 32) ------------------
+// The same rows, formed without a ring of prefix arrays in LDS and without a barrier.  With
+//   P^d[q] = sum_{j<q} D^d[j]  (exclusive prefix sum along diagonal d),  I^d[q] = P^d[q] + D^d[q],  tot^d = P^d[L2],
+// the row of offset s is  g_s[q] = P^{s-1}[q] + tot^{s-2} - I^{s-2}[q]:  everything position q needs of the
+// older diagonal is ONE value that stays with the lane that owns q.  A wave owns a whole chunk: lane l holds
+// the positions 64 k + l of every run k in registers (I^{d-1} and the Seq2 residue's table row), walks diagonal
+// after diagonal, run after run -- entry from the table in LDS, inclusive scan of the 64 entries by six
+// DPP adds, the run's total to a scalar register that carries the prefix into the next run -- and stores each
+// run of a row with one 256-byte instruction.  Nothing is exchanged between waves, so workgroups are single
+// waves that start wherever a wave slot is free (beside candidate loops that hold nearly every register, a
+// workgroup of 4 to 16 waves waited for a whole CU to drain).  Per 64 values of a row: 2 LDS reads, about 14
+// vector instructions, 1 store -- the block-wide form above spends, per value, five LDS accesses with strides
+// of R words, two barriers per offset and a shuffle-based scan, and wrote 0.7 to 1 TB/s of rows when it ran
+// alone; its time was a quarter of a list's whole step (Seq2 of 500 to 2000 characters).
+__device__ __forceinline__ int wave_scan_inclusive(int x) {
+  // rows of 16 lanes: Hillis-Steele with the row shifts; lanes shifted in from outside a row contribute 0
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+  // lane 15 of the row before into rows 1 and 3, then lane 31 into rows 2 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return x;
+}
+
+template <int R>
+struct PrepWaveLds {
+  static constexpr int itab = 0;                                   // kDevTable int32: the Seq2's fixed-point table
+  static constexpr int awin = kDevTable * 4;                       // Seq1 window: kEnumMaxNs + 64 R + 2 codes
+  static constexpr int total = awin + ((kEnumMaxNs + 64 * R + 2 + 15) / 16) * 16;
+};
+
+template <int R, bool F32>
+__global__ __launch_bounds__(64) void psa_enum_prep_wave(EnumParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using L = PrepWaveLds<R>;
+  const int lane = threadIdx.x;
+  const Chunk ch = load_chunk(P.chunks + blockIdx.x);
+  const SeqDesc d = load_desc(P.desc + ch.seq);
+  const int L2 = d.len2;
+  const int nruns = (L2 + 63) >> 6;  // <= R
+  const int npos = 64 * nruns;
+  int *itab = (int *)(smem + L::itab);
+  unsigned char *aw = smem + L::awin;
+  for (int i = lane; i < kDevTable; i += 64) itab[i] = __float2int_rn(ldexpf(P.table_t[i], d.frac_bits));
+  // byte offset of the table row of this lane's Seq2 residue in run k (positions past the end: the zero row)
+  int brow[R];
+  const unsigned char *b = P.seq2_pool + d.off2;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int q = 64 * k + lane;
+    brow[k] = (q < L2 ? (int)b[q] : kPadCode) * (kRowStride * 4);
+  }
+  // Seq1 codes met by the diagonals s0 - 2 .. s0 + ns - 1 at positions 0 .. npos - 1
+  const int win0 = ch.s0 - 2;
+  const int wlen = ch.ns + 2 + npos;
+  for (int i = lane; i < wlen; i += 64) {
+    const int64_t idx = (int64_t)win0 + i;
+    aw[i] = (idx >= 0 && idx < P.len1) ? P.seq1[idx] : (unsigned char)kPadCode;
+  }
+  __syncthreads();  // (one wave: orders the LDS writes above before the reads below)
+  int iprev[R];     // I^{d-1}[q] of this lane's positions
+  int tot_prev = 0;
+  const int qlast = (L2 - 1) & 63;  // lane of position L2 - 1 in the last run
+  int *row = P.fg + (size_t)ch.fg_row * 64;
+  // diagonal dd (relative to win0) -> with WRITE the row of offset win0 + dd + 1
+  auto walk = [&](int dd, bool write) {
+    int sbase = 0;  // P^d at the first position of the run: wave-uniform, carried in a scalar register
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (k < nruns) {
+        const int a = aw[dd + 64 * k + lane];
+        const int D = *(const int *)((const unsigned char *)itab + brow[k] + 4 * a);
+        const int inc = wave_scan_inclusive(D);
+        const int I = sbase + inc;
+        if (write) {
+          int g = I - D + tot_prev - iprev[k];
+          if (k == nruns - 1) {  // positions past the end of Seq2 repeat g[L2 - 1]
+            const int gl = __builtin_amdgcn_readlane(g, qlast);
+            g = lane > qlast ? gl : g;
+          }
+          row[64 * k + lane] = F32 ? __float_as_int((float)g) : g;
+        }
+        iprev[k] = I;
+        sbase += __builtin_amdgcn_readlane(inc, 63);
+      }
+    }
+    if (write) {
+      // one run of padding (rows must not start a power of two apart) whose first word is the row's constant
+      if (lane == 0) row[npos] = F32 ? __float_as_int((float)tot_prev) : tot_prev;
+      row += npos + 64;
+    }
+    tot_prev = sbase;
+  };
+#pragma unroll
+  for (int k = 0; k < R; ++k) iprev[k] = 0;
+  walk(0, false);                                             // diagonal s0 - 2
+  for (int dd = 1; dd <= ch.ns + 1; ++dd) walk(dd, true);     // diagonal s0 - 1 + i gives the row of offset s0 + i
+}
+
 // ---- candidate loop -----------------------------------------------------------------
 // The two instructions of the candidate loop, pinned: hipcc orders volatile asm
 // statements as written, and the order decides the speed here (see wave_full).
@@ -1173,9 +1274,35 @@ int enum_class_lds_bytes(int c) {
 
 int enum_class_threads(int c) { return c < 2 ? 256 : (c < 4 ? 512 : 1024); }
 
+template <int R>
+static hipError_t launch_prep_wave_t(const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (f32)
+    hipExtLaunchKernelGGL((psa_enum_prep_wave<R, true>), dim3(P.nchunks), dim3(64), (PrepWaveLds<R>::total), st, ev_start,
+                          ev_stop, 0, P);
+  else
+    hipExtLaunchKernelGGL((psa_enum_prep_wave<R, false>), dim3(P.nchunks), dim3(64), (PrepWaveLds<R>::total), st, ev_start,
+                          ev_stop, 0, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return debug_sync("psa_enum_prep_wave");
+}
+
 hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t st, hipEvent_t ev_start,
                             hipEvent_t ev_stop) {
   if (P.nchunks <= 0) return hipSuccess;
+  // Seq2 of up to 2047 characters (32 runs of 64 positions) in a large batch: one wave per chunk, rows held in
+  // registers; small batches and the longer Seq2 use the block-wide form
+  static const char *const force = getenv("PSA_PREP_FORM");  // tuning aid: "block" or "wave" for every batch
+  const bool wave_form = force ? force[0] == 'w' : P.prep_wave_form != 0;
+  if (wave_form) {
+    switch (cls) {
+      case 0: return launch_prep_wave_t<4>(P, f32, st, ev_start, ev_stop);
+      case 1: return launch_prep_wave_t<8>(P, f32, st, ev_start, ev_stop);
+      case 2: return launch_prep_wave_t<16>(P, f32, st, ev_start, ev_stop);
+      case 3: return launch_prep_wave_t<32>(P, f32, st, ev_start, ev_stop);
+      default: break;
+    }
+  }
   switch (cls) {
     case 0: return launch_prep_t<256, 1>(P, f32, st, ev_start, ev_stop);
     case 1: return launch_prep_t<256, 2>(P, f32, st, ev_start, ev_stop);

@@ -33,6 +33,9 @@ struct EnumParams {
   // over ALL shards, exchanged between the ranks after the candidate loops) instead of the shard's own
   int has_short_ref;
   int short_ref;
+  // pre-pass: one wave per chunk (throughput: batches of many slab passes) instead of one block per chunk
+  // (latency: a small batch's few hundred chunks, where the next candidate loop waits for this kernel)
+  int prep_wave_form;
 };
 
 // psa_enum_wave: one unit of work per (chunk, sub-run of its offsets, level).  Level w owns the
