@@ -593,6 +593,11 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
     }
   };
   class_bounds(0, (int)chunks.size(), b->cls_c0);
+  // PSA_ENUM_BAND=B (tuning aid): B adjacent levels of a sub-run side by side on one XCD (WaveParams).  Measured on
+  // one Seq2 of 8000 against a Seq1 of 200000: four times fewer bytes fetched into the L2s, and 3 to 10 % fewer
+  // candidates per second for every B from 2 to 32 -- level-major numbering stays the default.
+  int env_band = 0;
+  if (const char *e = std::getenv("PSA_ENUM_BAND")) env_band = std::max(0, std::atoi(e));
   for (psa_batch::SlabPass &sp : b->passes) {
     class_bounds(sp.c0, sp.c1, sp.cls_c0);
     psa::WaveParams &W = sp.wave;
@@ -613,6 +618,21 @@ static int batch_build(psa_ctx *c, int n, const char *const *seq2, const int32_t
       return PSA_ERR_ARG;
     }
     W.nunits = (int)base;
+    int band = env_band;
+    W.nlev = sp.c1 > sp.c0 ? levels_of(b->desc[(size_t)chunks[(size_t)sp.c0].seq].len2) : 1;
+    band = std::min(band, W.nlev);
+    W.band = band;
+    W.ncols = (sp.c1 - sp.c0) << sub_log2;
+    W.ncols8 = (W.ncols + 7) / 8 * 8;
+    if (band > 0) {
+      const int64_t nu = (int64_t)W.ncols8 * ((W.nlev + band - 1) / band * band);
+      if (nu > INT32_MAX) {
+        g_err = "too many enumeration units in one slab pass";
+        psa_batch_destroy(b);
+        return PSA_ERR_ARG;
+      }
+      W.nunits = (int)nu;
+    }
   }
 
   auto fail = [&](int code) {
@@ -811,11 +831,17 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
   const bool head = (parts & kPartHead) != 0, tail = (parts & kPartTail) != 0;
   // only a batch's first run, or one after a failed run, needs the set-up kernel
   const bool init = head && !b->acc_ready;
+  // The first run of a small one-pass batch (every one-shot call) is a chain set-up -> pre-pass -> candidate loop
+  // with nothing beside it: all three go on the candidate loop's stream, in order.  On three streams the two
+  // cross-stream waits cost about 20 us each, a sixth of such a call.
+  static const bool no_fast_start = std::getenv("PSA_NO_FAST_START") != nullptr;  // measurement aid
+  const bool fast_start = init && enumerate && b->passes.size() == 1 && b->setup_src && !no_fast_start;
+  hipStream_t st_fast = fast_start ? c->st_enum[c->enum_streams > 1 ? (c->enum_flip ^ 1) : 0] : nullptr;  // (the pass below takes it)
   if (init) {
     // on st_res, which never waits for a candidate loop
     if (b->setup_src) {
       PSA_HIP(psa::launch_setup_small(b->setup_src, b->d_pool, b->setup_bytes, b->d_acc, 2 * b->n, b->d_counters, 3,
-                                      b->d_chunk_best, 2 * (size_t)b->nchunks, c->st_res));
+                                      b->d_chunk_best, 2 * (size_t)b->nchunks, fast_start ? st_fast : c->st_res));
       PSA_HIP(psa::debug_sync("psa_setup_small"));
     } else {
       if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_upload, 0));
@@ -824,9 +850,13 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       if (b->nchunks > 0)
         PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, 2 * (size_t)b->nchunks * sizeof(unsigned long long), c->st_res));
     }
-    PSA_HIP(hipEventRecord(b->ev_init, c->st_res));
-    PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
-    for (hipStream_t st : c->st_enum) PSA_HIP(hipStreamWaitEvent(st, b->ev_init, 0));
+    PSA_HIP(hipEventRecord(b->ev_init, fast_start ? st_fast : c->st_res));
+    // (a fast start puts the other streams behind the set-up once its candidate loop is on its way: nothing
+    // of this batch reaches them before that)
+    if (!fast_start) {
+      PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
+      for (hipStream_t st : c->st_enum) PSA_HIP(hipStreamWaitEvent(st, b->ev_init, 0));
+    }
     b->tail_recorded[0] = b->tail_recorded[1] = false;
   }
   if (head) b->acc_ready = false;
@@ -878,7 +908,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       // a one-pass batch alternates between the slabs from run to run, so that the pre-pass of a
       // run enqueued behind another runs beside that one's candidate loop
       const int buf = piped ? sp.buf : (c->slab_flip = (c->slab_flip + 1) % c->nslabs);
-      if (c->slab_reader[buf]) PSA_HIP(hipStreamWaitEvent(c->st_pre, c->slab_reader[buf], 0));
+      hipStream_t st_prep = fast_start ? st_fast : c->st_pre;
+      if (c->slab_reader[buf]) PSA_HIP(hipStreamWaitEvent(st_prep, c->slab_reader[buf], 0));
       int last_cls = -1;
       for (int cls = 0; cls < psa::kEnumClasses; ++cls)
         if (sp.cls_c0[cls] > sp.cls_c0[cls + 1]) {
@@ -892,7 +923,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
         P.chunk_best = chunk_best + c0;
         P.nchunks = c1 - c0;
         P.fg = c->d_slab[buf];
-        PSA_HIP(psa::launch_enum_prep(cls, P, c->enum_f32, c->st_pre, ev_first,
+        PSA_HIP(psa::launch_enum_prep(cls, P, c->enum_f32, st_prep, ev_first,
                                       cls == last_cls ? c->ev_prep[buf] : nullptr));
         ev_first = nullptr;
       }
@@ -901,7 +932,7 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       // this run's copy of the accumulators was last used two runs ago, maybe on the other stream
       if (b->tail_recorded[par] && !last_loop[es] && b->tail_stream[par] != es)
         PSA_HIP(hipStreamWaitEvent(st_loop, b->ev_tail[par], 0));
-      PSA_HIP(hipStreamWaitEvent(st_loop, c->ev_prep[buf], 0));
+      if (st_loop != st_prep) PSA_HIP(hipStreamWaitEvent(st_loop, c->ev_prep[buf], 0));
       psa::WaveParams W = sp.wave;
       W.chunks = b->d_chunks + sp.c0;
       W.chunk_best = chunk_best + sp.c0;
@@ -941,7 +972,16 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
     b->head_last_loop[0] = last_loop[0];
     b->head_last_loop[1] = last_loop[1];
   }
-  if (enumerate && tail) {
+  if (fast_start) {
+    PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_init, 0));
+    PSA_HIP(hipStreamWaitEvent(c->st_pre, b->ev_init, 0));
+    for (hipStream_t st : c->st_enum)
+      if (st != st_fast) PSA_HIP(hipStreamWaitEvent(st, b->ev_init, 0));
+  }
+  // locate, the shortlist replay and the enumeration half of the records; behind the resolve chain in the host's
+  // order of enqueueing when the run is a fast start (the candidate loop gives the host time for both, and the
+  // resolve chain then runs beside the loop's first half instead of beside locate)
+  auto enqueue_tail = [&]() -> int {
     // locate and the records follow the last candidate loop on its stream; the candidate loops
     // of the next run start on the other stream, on the other copy of the accumulators
     const int es = b->head_es;
@@ -961,7 +1001,8 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       P.fg = nullptr;
       // few workgroups, each walking many chunks: nearly every chunk is skipped after two loads,
       // and a workgroup that reserves its LDS beside the candidate loops is slow to place
-      const int grid = std::min({c1 - c0, std::max(64, (c1 - c0) / 16), 4 * c->num_cus});
+      int grid = std::min({c1 - c0, std::max(64, (c1 - c0) / 16), 4 * c->num_cus});
+      if (const char *e = std::getenv("PSA_LOCATE_GRID")) grid = std::max(1, std::min(c1 - c0, std::atoi(e)));  // tuning aid
       PSA_HIP(psa::launch_enum_locate(cls, P, grid, st_tail));
     }
     if (P.short_rows) {
@@ -992,6 +1033,11 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
     b->tail_stream[par] = es;
     *timed = true;
     if (!resolve) b->enum_only_tail = b->ev_last;
+    return PSA_OK;
+  };
+  if (enumerate && tail && !fast_start) {
+    const int st = enqueue_tail();
+    if (st != PSA_OK) return st;
   }
   if (head && (resolve || !enumerate)) {
     // the record kernel of a run without the resolve stage (the run before this one) clears the
@@ -1030,6 +1076,10 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
     PSA_HIP(psa::launch_finalize(F, b->n, c->st_res, resolve ? nullptr : b->ev_res_first, b->ev_res));
     b->res_recorded = true;
     PSA_HIP(psa::debug_sync("psa_finalize"));
+  }
+  if (enumerate && tail && fast_start) {
+    const int st = enqueue_tail();
+    if (st != PSA_OK) return st;
   }
   if (tail) b->acc_ready = true;  // psa_finalize leaves the accumulators reset
   return PSA_OK;

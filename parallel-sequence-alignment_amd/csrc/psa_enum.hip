@@ -13,8 +13,8 @@
 // so every (s,p,q) costs one add and one max.
 //
 // Three kernels:
-//   psa_enum_prep    one workgroup per chunk of offsets: prefix sums of the diagonals in
-//                    LDS, then one row of g per offset into a slab in HBM.  f needs no row of
+//   psa_enum_prep    one workgroup (or, in large batches, one wave) per chunk of offsets: prefix
+//                    sums along the diagonals, then one row of g per offset into a slab in HBM.  f needs no row of
 //                    its own: g_{s+1}[p] = E^s[p] + E^{s-1}[L2] - E^{s-1}[p+1] = f_s[p] + E^{s-1}[L2],
 //                    so a chunk of ns offsets stores ns + 1 rows of g, each with its constant
 //                    (4 bytes per position and offset, against L2/2 candidates each);
@@ -137,54 +137,23 @@ __device__ __forceinline__ void enum_chunk_setup(unsigned char *smem, const Enum
 // offsets s0 .. s0+ns-1 stores the ns + 1 rows s0 .. s0+ns.
 // With F32 the values are stored as float32: the scale keeps |f|, |g| and the constants at or
 // below 2^24, so the conversion is exact.
-template <int NT, int R, bool F32>
-__global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int c = blockIdx.x;
-  const Chunk ch = load_chunk(P.chunks + c);
-  const SeqDesc d = load_desc(P.desc + ch.seq);
-  const int L2 = d.len2;
-  const int npos = 64 * ((L2 + 63) >> 6);
-  int bro[R];
-  int win0;
-  enum_chunk_setup<NT, R>(smem, P, ch, d, bro, win0);  // leaves diagonals s0 - 2 and s0 - 1 in the ring
-  int *row = P.fg + (size_t)ch.fg_row * 64;
-  for (int s = ch.s0; s <= ch.s0 + ch.ns; ++s) {
-    const int *E1 = ring_slot<NT, R>(smem, s - 1);
-    const int *E2 = ring_slot<NT, R>(smem, s - 2);
-    const int tot2 = E2[L2];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int p = r * NT + tid;
-      if (p < npos) {
-        const int qq = p > L2 - 1 ? L2 - 1 : p;
-        const int gv = E1[qq] + tot2 - E2[qq + 1];
-        row[p] = F32 ? __float_as_int((float)gv) : gv;
-      }
-    }
-    if (tid == 0) row[npos] = F32 ? __float_as_int((float)tot2) : tot2;
-    row += npos + 64;  // one run of padding: rows must not start a power of two apart
-    // diagonal s for the next row; the slot it overwrites (diagonal s - 3) was last read two
-    // rows ago, and the scan's first barrier comes after this row's reads of s - 2
-    if (s < ch.s0 + ch.ns) scan_diagonal<NT, R>(smem, bro, s, win0);
-  }
-}
+//
+// Two forms write the same rows.  Both rest on
+//   P^d[q] = sum_{j<q} D^d[j]  (exclusive prefix sum along diagonal d),  I^d[q] = P^d[q] + D^d[q],  tot^d = P^d[L2],
+//   g_s[q] = P^{s-1}[q] + tot^{s-2} - I^{s-2}[q]:
+// everything position q needs of the older diagonal is ONE value, which stays in a register of the lane that
+// owns q; no prefix array is kept in LDS.  A run of 64 positions is scanned by six DPP adds.
 
 // ---- pre-pass, one wave per chunk (Seq2 of at most 64 R positions, R <= 32) ------------------
-// The same rows, formed without a ring of prefix arrays in LDS and without a barrier.  With
-//   P^d[q] = sum_{j<q} D^d[j]  (exclusive prefix sum along diagonal d),  I^d[q] = P^d[q] + D^d[q],  tot^d = P^d[L2],
-// the row of offset s is  g_s[q] = P^{s-1}[q] + tot^{s-2} - I^{s-2}[q]:  everything position q needs of the
-// older diagonal is ONE value that stays with the lane that owns q.  A wave owns a whole chunk: lane l holds
+// No barrier at all: a wave owns a whole chunk.  Lane l holds
 // the positions 64 k + l of every run k in registers (I^{d-1} and the Seq2 residue's table row), walks diagonal
 // after diagonal, run after run -- entry from the table in LDS, inclusive scan of the 64 entries by six
 // DPP adds, the run's total to a scalar register that carries the prefix into the next run -- and stores each
 // run of a row with one 256-byte instruction.  Nothing is exchanged between waves, so workgroups are single
 // waves that start wherever a wave slot is free (beside candidate loops that hold nearly every register, a
 // workgroup of 4 to 16 waves waited for a whole CU to drain).  Per 64 values of a row: 2 LDS reads, about 14
-// vector instructions, 1 store -- the block-wide form above spends, per value, five LDS accesses with strides
-// of R words, two barriers per offset and a shuffle-based scan, and wrote 0.7 to 1 TB/s of rows when it ran
-// alone; its time was a quarter of a list's whole step (Seq2 of 500 to 2000 characters).
+// vector instructions, 1 store.  (Workgroups of 8 waves per chunk, beside the candidate loops of a long list,
+// took a quarter of the list's whole step: Seq2 of 500 to 2000 characters.)
 __device__ __forceinline__ int wave_scan_inclusive(int x) {
   // rows of 16 lanes: Hillis-Steele with the row shifts; lanes shifted in from outside a row contribute 0
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
@@ -270,6 +239,112 @@ __global__ __launch_bounds__(64) void psa_enum_prep_wave(EnumParams P) {
   for (int k = 0; k < R; ++k) iprev[k] = 0;
   walk(0, false);                                             // diagonal s0 - 2
   for (int dd = 1; dd <= ch.ns + 1; ++dd) walk(dd, true);     // diagonal s0 - 1 + i gives the row of offset s0 + i
+}
+
+// ---- pre-pass, one workgroup per chunk (small batches, where the next candidate loop waits for this
+// kernel, and Seq2 too long for one wave's registers) ------------------------------------------------
+// Thread t of NT owns the positions k NT + t, k = 0 .. R - 1: wave w of NW owns run k NW + w, and a row is
+// stored with one 256-byte instruction per wave and k.  The prefix at the start of a run needs the totals of
+// the runs before it, other waves' among them: every wave leaves its runs' totals in LDS, and after the one
+// barrier of the diagonal every wave scans the list of totals for itself (at most 128 of them, two registers).
+// The list is kept twice, for even and odd diagonals, so a wave may write the next diagonal's totals while
+// another still reads this one's.  LDS traffic per value: one byte of the Seq1 window (consecutive across
+// the lanes) and one table entry.
+template <int NT, int R>
+struct PrepBlockLds {
+  static constexpr int NW = NT / 64;
+  static constexpr int NRUN = R * NW;                               // runs of 64 positions covered (<= 128)
+  static constexpr int itab = 0;                                    // kDevTable int32
+  static constexpr int wtot = kDevTable * 4;                        // 2 x NRUN int32
+  static constexpr int awin = wtot + 2 * NRUN * 4;                  // Seq1 window: kEnumMaxNs + 64 NRUN + 2 codes
+  static constexpr int total = awin + ((kEnumMaxNs + 64 * NRUN + 2 + 15) / 16) * 16;
+};
+
+template <int NT, int R, bool F32>
+__global__ __launch_bounds__(NT) void psa_enum_prep(EnumParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using L = PrepBlockLds<NT, R>;
+  constexpr int NW = L::NW, NRUN = L::NRUN, NREG = (NRUN + 63) / 64;
+  static_assert(64 % NW == 0 && NRUN <= 128, "the list of run totals is scanned in at most two registers");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Chunk ch = load_chunk(P.chunks + blockIdx.x);
+  const SeqDesc d = load_desc(P.desc + ch.seq);
+  const int L2 = d.len2;
+  const int nruns = (L2 + 63) >> 6;  // <= NRUN
+  const int npos = 64 * nruns;
+  int *itab = (int *)(smem + L::itab);
+  int *wtot = (int *)(smem + L::wtot);
+  unsigned char *aw = smem + L::awin;
+  for (int i = tid; i < kDevTable; i += NT) itab[i] = __float2int_rn(ldexpf(P.table_t[i], d.frac_bits));
+  int brow[R];  // byte offset of the table row of this thread's Seq2 residue (positions past the end: the zero row)
+  const unsigned char *b = P.seq2_pool + d.off2;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int q = k * NT + tid;
+    brow[k] = (q < L2 ? (int)b[q] : kPadCode) * (kRowStride * 4);
+  }
+  const int win0 = ch.s0 - 2;
+  const int wlen = ch.ns + 2 + npos;
+  for (int i = tid; i < wlen; i += NT) {
+    const int64_t idx = (int64_t)win0 + i;
+    aw[i] = (idx >= 0 && idx < P.len1) ? P.seq1[idx] : (unsigned char)kPadCode;
+  }
+  __syncthreads();
+  int iprev[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) iprev[k] = 0;
+  int tot_prev = 0;
+  const int qlast = (L2 - 1) & 63;
+  int *row = P.fg + (size_t)ch.fg_row * 64;
+  for (int dd = 0; dd <= ch.ns + 1; ++dd) {  // diagonal s0 - 2 + dd; from dd = 1 on it gives the row of offset s0 - 1 + dd
+    int *wt = wtot + (dd & 1) * NRUN;
+    int D[R], inc[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int rr = k * NW + w;
+      D[k] = 0;
+      inc[k] = 0;
+      if (rr < nruns) {
+        const int a = aw[dd + k * NT + tid];
+        D[k] = *(const int *)((const unsigned char *)itab + brow[k] + 4 * a);
+        inc[k] = wave_scan_inclusive(D[k]);
+        if (lane == 63) wt[rr] = inc[k];
+      }
+    }
+    __syncthreads();
+    int excl[NREG];
+    int tot = 0;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+      const int x = 64 * j + lane < nruns ? wt[64 * j + lane] : 0;
+      const int sc = wave_scan_inclusive(x);
+      excl[j] = sc - x + tot;
+      tot += __builtin_amdgcn_readlane(sc, 63);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int rr = k * NW + w;
+      if (rr < nruns) {
+        const int I = __builtin_amdgcn_readlane(excl[(k * NW) >> 6], rr & 63) + inc[k];
+        if (dd > 0) {
+          int g = I - D[k] + tot_prev - iprev[k];
+          if (rr == nruns - 1) {  // positions past the end of Seq2 repeat g[L2 - 1]
+            const int gl = __builtin_amdgcn_readlane(g, qlast);
+            g = lane > qlast ? gl : g;
+          }
+          row[64 * rr + lane] = F32 ? __float_as_int((float)g) : g;
+        }
+        iprev[k] = I;
+      }
+    }
+    if (dd > 0) {
+      // one run of padding (rows must not start a power of two apart) whose first word is the row's constant
+      if (tid == 0) row[npos] = F32 ? __float_as_int((float)tot_prev) : tot_prev;
+      row += npos + 64;
+    }
+    tot_prev = tot;
+  }
 }
 
 // ---- candidate loop -----------------------------------------------------------------
@@ -635,6 +710,28 @@ __device__ __forceinline__ void mfma_own_level(const int (&g)[4], const i32x2 (&
   }
 }
 
+// unit number -> (chunk c, sub-run j, level w); false if the unit is empty
+__device__ __forceinline__ bool decode_unit(const WaveParams &P, int u, int &c, int &j, int &w) {
+  if (P.band > 0) {
+    const int per_band = P.ncols8 * P.band;
+    const int b = u / per_band, r = u - b * per_band;
+    const int g = r / (8 * P.band), rr = r - g * 8 * P.band;
+    w = b * P.band + (rr >> 3);
+    const int col = (g << 3) + (rr & 7);
+    if (col >= P.ncols || w >= P.nlev) return false;
+    c = col >> P.sub_log2;
+    j = col & ((1 << P.sub_log2) - 1);
+    return true;
+  }
+  w = 0;
+#pragma unroll
+  for (int i = 1; i < kEnumMaxLevels; ++i) w += (u >= P.level_base[i]) ? 1 : 0;
+  const int mu = u - P.level_base[w];
+  c = mu >> P.sub_log2;
+  j = mu & ((1 << P.sub_log2) - 1);
+  return true;
+}
+
 // One unit with every candidate's sum formed on the matrix cores: sub-run j of chunk c at level w
 // (positions p in [256 w, 256 w + 256) as 8 blocks of 32; q from 256 w to the end of the row in
 // blocks of 32).  The row of an offset is read through per-lane loads of 64 consecutive values,
@@ -648,11 +745,8 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     stamp_c = __builtin_amdgcn_s_memtime();
     stamp_r = __builtin_amdgcn_s_memrealtime();
   }
-  int w = 0;
-#pragma unroll
-  for (int i = 1; i < kEnumMaxLevels; ++i) w += (u >= P.level_base[i]) ? 1 : 0;
-  const int mu = u - P.level_base[w];
-  const int c = mu >> P.sub_log2, j = mu & ((1 << P.sub_log2) - 1);
+  int c, j, w;
+  if (!decode_unit(P, u, c, j, w)) return;
   const Chunk ch = load_chunk(P.chunks + c);
   const SeqDesc d = load_desc(P.desc + ch.seq);
   const int r0 = j * d.enum_ns;
@@ -660,6 +754,7 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
   const int r1 = min(r0 + d.enum_ns, ch.ns);
   const int L2 = d.len2;
   const int nruns = (L2 + 63) >> 6;
+  if (4 * w >= nruns) return;    // (banded numbering: this Seq2 has fewer levels than the launch's longest)
   const int qend = 64 * nruns;   // row length
   const int pc0 = 4 * w;         // first run of 64 positions p of this level
   const int q00 = 64 * pc0;      // first position of the level
@@ -871,11 +966,8 @@ struct WaveOwn<R, -1, F32> {
 // One unit: sub-run j of chunk c at level w (positions p in [256 w, 256 w + 256)).
 template <int R, bool F32>
 __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const WaveParams &P, int u, int lane) {
-  int w = 0;
-#pragma unroll
-  for (int i = 1; i < kEnumMaxLevels; ++i) w += (u >= P.level_base[i]) ? 1 : 0;
-  const int m = u - P.level_base[w];
-  const int c = m >> P.sub_log2, j = m & ((1 << P.sub_log2) - 1);
+  int c, j, w;
+  if (!decode_unit(P, u, c, j, w)) return;
   const Chunk ch = load_chunk(P.chunks + c);
   const SeqDesc d = load_desc(P.desc + ch.seq);
   const int r0 = j * d.enum_ns;
@@ -883,6 +975,7 @@ __device__ __forceinline__ void wave_unit(const int *__restrict__ fg, const Wave
   const int r1 = min(r0 + d.enum_ns, ch.ns);
   const int L2 = d.len2;
   const int nruns = (L2 + 63) >> 6;
+  if (R * w >= nruns) return;  // (banded numbering: this Seq2 has fewer levels than the launch's longest)
   const int qend = 64 * nruns;           // row length
   const int qlast = (L2 + 15) & ~15;     // the candidate loop stops at the 16-value step that holds q = L2 - 1
   const int pc0 = w * R;
@@ -986,10 +1079,16 @@ __global__ __launch_bounds__(512, 4) void psa_enum_wave_mfma(const int *__restri
 // waves per SIMD the locate kernel's register budget is sized for
 constexpr int enum_waves_per_simd(int nt, int r) { return nt * r > 4096 ? 4 : 8; }
 
+// maximum over the wave, in every lane: rows of 16 lanes by row shifts (a lane without a source keeps its own
+// value), then lane 15 of rows 0 and 2 into rows 1 and 3, lane 31 into rows 2 and 3; lane 63 holds the result
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
-  return v;
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Second pass, two jobs on the chunks worth revisiting (nearly every chunk is skipped after three
@@ -1138,14 +1237,14 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
           for (int k = 0; k < np; ++k) {
             const int p = plist[k];
             const int fp = Es[p] - E1[p + 1];
+            // the 64 positions a wave holds in register r lie in one 256-wide block of q: its bit is set if any
+            // lane has a candidate (a compare into a scalar mask -- no exchange between lanes)
             unsigned mask = 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               const int q = r * NT + tid;
-              if (q > p && fp + gq[r] >= T) mask |= 1u << (q >> 8);
+              if (__ballot(q > p && fp + gq[r] >= T)) mask |= 1u << ((r * NT + 64 * w) >> 8);
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) mask |= (unsigned)__shfl_xor((int)mask, m);
             if (lane == 0 && mask) atomicOr(&pmask[k], mask);
           }
           __syncthreads();
@@ -1188,13 +1287,7 @@ __global__ __launch_bounds__(NT, enum_waves_per_simd(NT, R)) void psa_enum_locat
 // called by psa_init), not remembered in a process-wide flag.
 template <int NT, int R>
 static hipError_t set_lds_attr() {
-  using L = EnumLds<NT, R>;
-  hipError_t e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R, false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)psa_enum_prep<NT, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          L::total);
-  if (e != hipSuccess) return e;
+  using L = EnumLds<NT, R>;  // (the pre-pass needs less than the default limit)
   return hipFuncSetAttribute((const void *)psa_enum_locate<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
 }
 
@@ -1213,10 +1306,10 @@ static hipError_t launch_prep_t(const EnumParams &P, bool f32, hipStream_t st, h
                                 hipEvent_t ev_stop) {
   hipError_t e;
   if (f32)
-    hipExtLaunchKernelGGL((psa_enum_prep<NT, R, true>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st,
+    hipExtLaunchKernelGGL((psa_enum_prep<NT, R, true>), dim3(P.nchunks), dim3(NT), (PrepBlockLds<NT, R>::total), st,
                           ev_start, ev_stop, 0, P);
   else
-    hipExtLaunchKernelGGL((psa_enum_prep<NT, R, false>), dim3(P.nchunks), dim3(NT), (EnumLds<NT, R>::total), st,
+    hipExtLaunchKernelGGL((psa_enum_prep<NT, R, false>), dim3(P.nchunks), dim3(NT), (PrepBlockLds<NT, R>::total), st,
                           ev_start, ev_stop, 0, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_enum_prep");
@@ -1292,7 +1385,7 @@ hipError_t launch_enum_prep(int cls, const EnumParams &P, bool f32, hipStream_t 
   if (P.nchunks <= 0) return hipSuccess;
   // Seq2 of up to 2047 characters (32 runs of 64 positions) in a large batch: one wave per chunk, rows held in
   // registers; small batches and the longer Seq2 use the block-wide form
-  static const char *const force = getenv("PSA_PREP_FORM");  // tuning aid: "block" or "wave" for every batch
+  const char *const force = getenv("PSA_PREP_FORM");  // tuning aid: "block" or "wave" for every batch
   const bool wave_form = force ? force[0] == 'w' : P.prep_wave_form != 0;
   if (wave_form) {
     switch (cls) {

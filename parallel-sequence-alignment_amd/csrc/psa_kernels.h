@@ -50,6 +50,16 @@ struct WaveParams {
   int sub_log2;                            // sub-runs per chunk = 1 << sub_log2
   int level_base[kEnumMaxLevels + 1];      // first unit of each level; unused entries hold INT_MAX
   int nunits;
+  // Banded numbering (band > 0): workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2, and a
+  // row of g is read by every level of its chunk.  The levels are taken in bands of `band` adjacent ones, band
+  // after band (largest units first, as in level-major numbering); within a band, unit r belongs to column
+  // (sub-run of a chunk) 8 (r / (8 band)) + r % 8 and level r / 8 % band of the band: the band's levels of a
+  // column run on ONE XCD, side by side, and read the column's rows from that XCD's L2.  Columns past ncols
+  // and levels past nlev (the counts are rounded up to 8 and to the band) are empty units.
+  int band;      // 0: level-major numbering
+  int nlev;      // levels of the launch's longest Seq2
+  int ncols;     // sub-runs of all chunks of the launch
+  int ncols8;    // ncols rounded up to a multiple of 8
   // diagnostic (null in normal runs): 64 slots of 8 words; a unit adds to slot (unit & 63):
   // [0] += shader cycles, [1] += 100 MHz ticks, [2] += 1
   unsigned long long *clock_probe;

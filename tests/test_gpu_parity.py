@@ -961,6 +961,28 @@ def test_slab_passes(psa, oracle, monkeypatch):
         c.close()
 
 
+def test_prepass_forms_and_unit_numbering(psa, oracle, monkeypatch):
+    """The tuning switches that change how the enumeration is laid out, not what it returns: PSA_PREP_FORM
+    (pre-pass by one workgroup or one wave per chunk, for every batch instead of by batch size) and
+    PSA_ENUM_BAND (candidate-loop units numbered in bands of levels per XCD): same records as the defaults."""
+    lens = [40, 300, 511, 512, 700, 1100, 2047, 2048, 2100, 4100]
+    seq1, seq2s = synth_problem(93, 4300, lens)
+    w = np.array([2, 1.5, 1.1, 1.3], dtype=np.float32)
+    monkeypatch.setenv("PSA_SLAB_MB", "5")
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(w)
+    res = c.score_batch(seq2s)
+    check_against_oracle(oracle, seq1, seq2s, oracle.comp_matrix(w), res)
+    want = [bytes(r) for r in res]
+    for name, value in (("PSA_PREP_FORM", "block"), ("PSA_PREP_FORM", "wave"), ("PSA_ENUM_BAND", "2"),
+                        ("PSA_ENUM_BAND", "3"), ("PSA_ENUM_BAND", "64")):
+        monkeypatch.setenv(name, value)
+        assert [bytes(r) for r in c.score_batch(seq2s)] == want, (name, value)
+        monkeypatch.delenv(name)
+    c.close()
+
+
 def test_stream_of_batches(psa, oracle):
     """Several batches of one context enqueued back to back before any is waited for: they share
     the context's slabs, streams and recycled buffers, and each returns what it returns alone."""
