@@ -130,7 +130,7 @@ struct psa_batch {
   unsigned char *d_pool = nullptr;
   psa::SeqDesc *d_desc = nullptr;
   psa::SeqAcc *d_acc = nullptr;
-  unsigned *d_counters = nullptr;  // [0] = the active-offset count
+  unsigned *d_counters = nullptr;  // [0] = the active-offset count, [1], [2] = shortlist rows of the two runs in flight, [3], [4] = their record blocks done
   // enumeration stage: chunks sorted by falling Seq2 length; a slab pass covers chunks
   // [c0, c1), whose rows fit one slab
   struct SlabPass {
@@ -840,12 +840,12 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
   if (init) {
     // on st_res, which never waits for a candidate loop
     if (b->setup_src) {
-      PSA_HIP(psa::launch_setup_small(b->setup_src, b->d_pool, b->setup_bytes, b->d_acc, 2 * b->n, b->d_counters, 3,
+      PSA_HIP(psa::launch_setup_small(b->setup_src, b->d_pool, b->setup_bytes, b->d_acc, 2 * b->n, b->d_counters, 5,
                                       b->d_chunk_best, 2 * (size_t)b->nchunks, fast_start ? st_fast : c->st_res));
       PSA_HIP(psa::debug_sync("psa_setup_small"));
     } else {
       if (b->upload_in_flight) PSA_HIP(hipStreamWaitEvent(c->st_res, b->ev_upload, 0));
-      PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 3, c->st_res));
+      PSA_HIP(psa::launch_init(b->d_acc, 2 * b->n, b->d_counters, 5, c->st_res));
       PSA_HIP(psa::debug_sync("psa_init_acc"));
       if (b->nchunks > 0)
         PSA_HIP(hipMemsetAsync(b->d_chunk_best, 0, 2 * (size_t)b->nchunks * sizeof(unsigned long long), c->st_res));
@@ -1018,7 +1018,13 @@ static int enqueue_run(psa_batch *b, uint32_t stages, bool *timed, unsigned part
       R.short_rows_cap = P.short_rows_cap;
       R.short_quota = P.short_quota;
       R.eacc = eacc;
-      PSA_HIP(psa::launch_short_replay(R, b->max_len2, std::max(256, std::min(4096, b->nvalid * R.pchunks * 8)), st_tail));
+      // (a small batch: the record kernel picks the offsets itself, one launch less behind the candidate loop)
+      const bool pick_in_records = b->nvalid <= 8;
+      PSA_HIP(psa::launch_short_replay(R, b->max_len2, std::max(256, std::min(4096, b->nvalid * R.pchunks * 8)),
+                                       !pick_in_records, st_tail));
+      F.pick_rows = pick_in_records ? P.short_rows : nullptr;
+      F.pick_rows_cap = P.short_rows_cap;
+      F.pick_done = b->d_counters + 3 + par;
     }
     F.which = resolve ? PSA_STAGE_ENUMERATE : (PSA_STAGE_ENUMERATE | PSA_STAGE_RESOLVE);
     // Record kernels of runs without the resolve stage clear the float32 half of the records.  Two

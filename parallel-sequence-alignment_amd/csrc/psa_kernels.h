@@ -101,6 +101,11 @@ struct FinalParams {
   ShortOut *short_out;    // ... which reports the replayed winners here (pinned host memory)
   int short_quota;        // rows one Seq2 may list before it is given up
   int short_empty_ok;     // a list without a row is complete (state 1, no winner): shards of a long pair, see EnumParams::short_ref
+  // small batches: the enumeration half also picks each Seq2's smallest offset among its winning rows
+  // (psa_short_pick's job: one launch less behind the candidate loop); null otherwise
+  const ShortRow *pick_rows;
+  int pick_rows_cap;
+  unsigned *pick_done;    // blocks that have read the list: the last one resets its row counter
 };
 
 int enum_class_of(int len2);          // -1 if len2 is too long
@@ -129,7 +134,7 @@ hipError_t launch_enum_wave(const int *fg, const WaveParams &P, bool f32, bool u
 hipError_t launch_enum_locate(int cls, const EnumParams &P, int grid, hipStream_t st);
 // float32 replay of the shortlist rows that locate appended (P.short_rows, P.short_total, P.eacc), then the
 // smallest offset among the rows that attain each Seq2's best
-hipError_t launch_short_replay(const ResolveParams &P, int max_len2, int grid, hipStream_t st);
+hipError_t launch_short_replay(const ResolveParams &P, int max_len2, int grid, bool pick, hipStream_t st);
 hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2, int tie_grid, hipStream_t st,
                           hipEvent_t ev_start);
 hipError_t launch_finalize(const FinalParams &P, int n, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);

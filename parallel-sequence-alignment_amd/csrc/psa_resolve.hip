@@ -637,16 +637,20 @@ __device__ __forceinline__ void first_q_body(const ResolveParams &P) {
 __global__ __launch_bounds__(256) void psa_first_q(ResolveParams P) { first_q_body<false>(P); }
 __global__ __launch_bounds__(256) void psa_short_rows(ResolveParams P) { first_q_body<true>(P); }
 
+// a row's best candidate as the key its Seq2 keeps the maximum of: (score, smallest p, smallest q)
+__device__ __forceinline__ unsigned long long short_row_key(const ShortRow &r) {
+  const unsigned long long qmin = 0xffffffffu - (uint32_t)r.best;
+  return (r.best & 0xffffffff00000000ull) | ((unsigned long long)(0xffffu - r.p) << 16) | (0xffffull - qmin);
+}
+
 // The smallest offset among the rows whose best candidate is their Seq2's best (score, p, q).
 __global__ __launch_bounds__(256) void psa_short_pick(ResolveParams P) {
   const unsigned n = min(*P.short_total, (unsigned)P.short_rows_cap);
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const ShortRow r = P.short_rows[i];
     if (r.best == 0ull) continue;
-    const unsigned long long qmin = 0xffffffffu - (uint32_t)r.best;
-    const unsigned long long k = (r.best & 0xffffffff00000000ull) | ((unsigned long long)(0xffffu - r.p) << 16) | (0xffffull - qmin);
     SeqAcc *a = P.eacc + r.seq;
-    if (a->short_count <= (unsigned)P.short_quota && k == a->short_best) atomicMin(&a->short_s, (uint32_t)r.s);
+    if (a->short_count <= (unsigned)P.short_quota && short_row_key(r) == a->short_best) atomicMin(&a->short_s, (uint32_t)r.s);
   }
 }
 
@@ -694,15 +698,41 @@ __device__ void count_classes(const FinalParams &P, const SeqDesc &d, int s, int
 // that produce their inputs, so the resolve half is done long before the enumeration ends.
 __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
   __shared__ int lds_counts[4];
+  __shared__ unsigned lds_pick;
   __shared__ __align__(4) unsigned char lds_class[kDevTable];
   const int i = blockIdx.x;
   static_assert(kDevTable % 4 == 0 && kDevTable / 4 <= 256, "one 4-byte load per thread");
   if (threadIdx.x < kDevTable / 4) ((uint32_t *)lds_class)[threadIdx.x] = ((const uint32_t *)P.class_t)[threadIdx.x];
   const SeqDesc d = P.desc[i];
   const SeqAcc a = P.acc[i];
-  const SeqAcc ea = P.eacc[i];
+  SeqAcc ea = P.eacc[i];
   psa_result *r = P.out + i;
   const int tid = threadIdx.x;
+  if (uni((int)((P.which & PSA_STAGE_ENUMERATE) && P.pick_rows != nullptr))) {
+    // this Seq2's smallest offset among the rows whose best candidate is its best (every block reads the whole
+    // list: a small batch's)
+    if (tid == 0) lds_pick = ~0u;
+    __syncthreads();
+    if (ea.short_count <= (unsigned)P.short_quota && ea.short_best != 0ull) {
+      const unsigned n = min(*P.short_total, (unsigned)P.pick_rows_cap);
+      unsigned best_s = ~0u;
+      for (unsigned k = tid; k < n; k += 256u) {
+        const ShortRow row = P.pick_rows[k];
+        if (row.seq == i && row.best != 0ull && short_row_key(row) == ea.short_best) best_s = min(best_s, (uint32_t)row.s);
+      }
+      if (best_s != ~0u) atomicMin(&lds_pick, best_s);
+    }
+    __syncthreads();
+    ea.short_s = lds_pick;
+    if (tid == 0) {
+      // every block reads the row counter: the last one to have done so resets it for the next run
+      __threadfence();
+      if (atomicAdd(P.pick_done, 1u) == gridDim.x - 1u) {
+        *P.short_total = 0u;
+        *P.pick_done = 0u;
+      }
+    }
+  }
   // Each half is the last reader of its accumulators in a run and leaves them reset for the
   // next one (what psa_init_acc writes), so a resident batch needs no set-up kernel per run.
   __syncthreads();
@@ -722,7 +752,8 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
       P.eacc[i].short_best = 0ull;
       P.eacc[i].short_s = ~0u;
       P.eacc[i].short_count = 0u;
-      if (i == 0 && P.short_total) *P.short_total = 0u;  // (its readers ran before this kernel on the same stream)
+      // (its readers ran before this kernel on the same stream -- unless the blocks of this kernel read it)
+      if (i == 0 && P.short_total && !P.pick_rows) *P.short_total = 0u;
     }
   }
   if (uni((int)(P.which & PSA_STAGE_RESOLVE))) {
@@ -785,7 +816,14 @@ __global__ __launch_bounds__(256) void psa_finalize(FinalParams P) {
         const int p = (int)(0xffffu - (uint32_t)((ea.short_best >> 16) & 0xffffu));
         const int q = (int)(0xffffu - (uint32_t)(ea.short_best & 0xffffu));
         const int s = (int)ea.short_s;
-        count_classes(P, d, s, p, q, lds_class, lds_counts, so->counts);
+        // (the replayed winner is nearly always the enumerated one, whose counts are still in LDS)
+        const bool same = uni((int)(p == (int)(0xffffffffu - (uint32_t)ea.enum_key) && q == (int)(ea.enum_loc >> 32) &&
+                                    s == (int)(uint32_t)ea.enum_loc));
+        if (same) {
+          if (tid < 4) so->counts[tid] = lds_counts[tid];
+        } else {
+          count_classes(P, d, s, p, q, lds_class, lds_counts, so->counts);
+        }
         if (tid == 0) {
           so->score_bits = __float_as_uint(key2f((uint32_t)(ea.short_best >> 32)));
           so->n = p + 1;
@@ -901,12 +939,13 @@ hipError_t launch_resolve(const ResolveParams &P, int nfwd_blocks, int max_len2,
   return debug_sync("psa_first_q");
 }
 
-hipError_t launch_short_replay(const ResolveParams &P, int max_len2, int grid, hipStream_t st) {
+hipError_t launch_short_replay(const ResolveParams &P, int max_len2, int grid, bool pick, hipStream_t st) {
   if (!P.short_rows) return hipSuccess;
   hipLaunchKernelGGL(psa_short_rows, dim3(grid), dim3(256), tie_lds(max_len2), st, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if ((e = debug_sync("psa_short_rows")) != hipSuccess) return e;
+  if (!pick) return hipSuccess;  // (psa_finalize picks: FinalParams::pick_rows)
   hipLaunchKernelGGL(psa_short_pick, dim3(std::max(1, std::min(1024, P.short_rows_cap / 256))), dim3(256), 0, st, P);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return debug_sync("psa_short_pick");
