@@ -9,7 +9,7 @@ out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --stages resolve --sync-steps --steps 300 --no-cpu-baseline --no-scale --no-host-inclusive > $out/stats.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --stages resolve --sync-steps --steps 300 --no-cpu-baseline --no-scale --no-host-inclusive --no-boundary --repeats 0 > $out/stats.log 2>&1 || exit 1
 cd $R
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/${tag}_resolve_kernel_stats.csv
