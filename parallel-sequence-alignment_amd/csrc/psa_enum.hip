@@ -554,8 +554,8 @@ __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int
 
 // ---- candidate sums on the matrix cores --------------------------------------------------
 // f[p] + g[q] for 32 q x 32 p is the product of a 32 x K and a K x 32 matrix whose entries are
-// pieces of the values and ones: sum_k A[q][k] B[k][p] with A = (g_hi, g_mid, g_lo, 0, 1, 1, 1, 0),
-// B = (1, 1, 1, 0, f_hi, f_mid, f_lo, 0).  f and g are integers of at most 25 significant bits held in
+// pieces of the values and ones: sum_k A[q][k] B[k][p] with A = (g_hi, g_mid, 0, g_lo, 1, 1, 0, 1),
+// B = (1, 1, 0, 1, f_hi, f_mid, 0, f_lo).  f and g are integers of at most 25 significant bits held in
 // float32, so each splits exactly into three bfloat16 values (8 significant bits each): hi = the
 // value with its low 16 bits cleared, mid likewise of the remainder, lo the rest.  Every product
 // is exact, every partial sum of pieces is an integer no larger than the larger of |f|, |g| and
@@ -571,8 +571,10 @@ __device__ __forceinline__ void wave_full(const int *__restrict__ G, int qa, int
 // element j = 0..3 (two per operand register); result register v of lane l is row
 // (v & 3) + 8 (v >> 2) + 4h, column r.  Columns are positions p (a lane keeps the running maximum
 // of its own p over the rows, i.e. over q), rows are positions q.  So
-//   A: lanes  0..31 (k = 0..3) = (g_hi | g_mid), (g_lo | 0) of row r;   lanes 32..63 (k = 4..7) = (1 | 1), (1 | 0)
-//   B: lanes  0..31            = (1 | 1), (1 | 0);   lanes 32..63 = (f_hi | f_mid), (f_lo | 0) of column r
+//   A: lanes  0..31 (k = 0..3) = (g_hi | g_mid), (0 | g_lo) of row r;   lanes 32..63 (k = 4..7) = (1 | 1), (0 | 1)
+//   B: lanes  0..31            = (1 | 1), (0 | 1);   lanes 32..63 = (f_hi | f_mid), (0 | f_lo) of column r
+// (the low piece sits in the upper half of its register: it has at most 8 significant bits, so the float32 itself,
+// whose lower 16 bits are zero, IS the pair (0 | lo) -- no shift)
 // With the packed pieces of 64 consecutive values in two registers (lane = position),
 // v_permlane32_swap_b32 against a register of ones yields the operand registers of BOTH blocks of
 // 32 at once: it exchanges the upper half of its first register with the lower half of its second.
@@ -580,9 +582,9 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) int i32x2;
 constexpr int kOnesBf16 = 0x3f803f80;   // (1.0, 1.0) as two bfloat16
-constexpr int kOneLoBf16 = 0x00003f80;  // (1.0, 0.0)
+constexpr int kOneLoBf16 = 0x3f800000;  // (0.0, 1.0)
 
-// x = hi + mid + lo exactly; p0 = (hi | mid << 16), p1 = (lo | 0) as packed bfloat16
+// x = hi + mid + lo exactly; p0 = (hi | mid << 16), p1 = (0 | lo << 16) as packed bfloat16
 __device__ __forceinline__ void split_bf16x3(int xbits, int &p0, int &p1) {
   const float x = __int_as_float(xbits);
   const int hi = xbits & (int)0xffff0000;
@@ -590,7 +592,7 @@ __device__ __forceinline__ void split_bf16x3(int xbits, int &p0, int &p1) {
   const int mid = __float_as_int(rem) & (int)0xffff0000;
   const float lo = rem - __int_as_float(mid);
   p0 = (int)__builtin_amdgcn_perm((unsigned)mid, (unsigned)hi, 0x07060302u);
-  p1 = (int)((unsigned)__float_as_int(lo) >> 16);
+  p1 = __float_as_int(lo);
 }
 
 // B operands of the wave's 8 blocks of 32 positions p from its 4 registers of f (lane = position):
@@ -761,8 +763,14 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
   const int rowlen = qend + 64;  // a row of g and its run of padding
   const int *__restrict__ G = fg + ((size_t)ch.fg_row + (size_t)r0 * (nruns + 1)) * 64;  // row of offset r0
   const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, -1, 0x00020000);
+  // Every per-lane load of the unit is the lane's byte offset inside a run of 64 values (ONE vector register) plus a
+  // scalar offset: the row, the run and the clamps are wave-uniform and cost scalar instructions only.
+  const int vl = 4 * lane;
   // Register r of f holds run pc0 + r of p; past the last run it repeats that run (its maxima are dropped below).
-  auto vb = [&](int r) { return 4 * (64 * min(pc0 + r, nruns - 1) + lane); };  // recomputed where used: no registers held
+  auto sb = [&](int r) { return 256 * min(pc0 + r, nruns - 1); };
+  // the rows' constants are read through the scalar cache, from an address the compiler knows to be wave-uniform
+  const char *const Gs = (const char *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uintptr_t)G >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)G));
   // mask of a diagonal tile: result register v of this lane is row (v & 3) + 8 (v >> 2) + 4 (lane >> 5), column lane & 31
   f32x16 mask;
 #pragma unroll
@@ -779,14 +787,14 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
   //   fn[r]  next offset's f (its row is the one after this offset's), run pc0 + r of p
   //   gn[k]  next offset's g for the level's own 256 positions, run pc0 + k
   const int step = 4 * rowlen;  // bytes from one offset's row to the next
-  auto vq = [&](int q) { return 4 * (min(q, qend) + lane); };  // past the row: its run of padding
+  auto sq = [&](int q) { return 4 * min(q, qend); };  // past the row: its run of padding
   int fn[4], gn[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), soff + step, 0);
-    gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q00 + 64 * r), soff, 0);
+    fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, soff + step + sb(r), 0);
+    gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, soff + sq(q00 + 64 * r), 0);
   }
-  int tn = G[rowlen + qend];  // the constant of the next row
+  int tn = *(const int *)(Gs + (step + 4 * qend));  // the constant of the next row
 #ifdef PSA_TRACE
   unsigned long long tr_top = 0, tr_own = 0, tr_long = 0, tr_t;
 #define PSA_TR(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tr_t; tr_t = n_; }
@@ -808,21 +816,20 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     const int grow = soff;  // this offset's row of g
     const int adv = i + 1 < r1 ? step : 0;  // the last offset of the unit requests its own rows again
     soff += step;
-    G += rowlen;
     {
       const int nrow = grow + adv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vb(r), nrow + step, 0);
-        gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q00 + 64 * r), nrow, 0);
+        fn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, nrow + step + sb(r), 0);
+        gn[r] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, nrow + sq(q00 + 64 * r), 0);
       }
-      tn = (G - rowlen)[(adv ? 2 : 1) * rowlen + qend];
+      tn = *(const int *)(Gs + (nrow + step + 4 * qend));
     }
     int q = q00 + 256;
     // the first three steps beyond the level's own positions, requested before those are scored
     int g[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g[k] = __builtin_amdgcn_raw_buffer_load_b32(rows, vq(q + 64 * k), grow, 0);  // (used ~36 tiles later)
+    for (int k = 0; k < 3; ++k) g[k] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, grow + sq(q + 64 * k), 0);  // (used ~36 tiles later)
     // the level's own 256 positions: blocks 0..7 of q against the blocks of p below and at them
 #define PSA_OWN_STEP(K)                                                          \
     if (q00 + 64 * K < qend) {                                                     \
@@ -845,14 +852,28 @@ __device__ __forceinline__ void wave_unit_mfma(const int *__restrict__ fg, const
     // beyond them every (p, q) pair is a candidate; the row is requested three steps ahead into
     // four registers that take turns (no copies, and a wait only ever covers a load three steps old)
     const f32x16 z = {};
-    for (; q < qend; q += 256) {
+    // four whole steps at a time while the row has them (no condition inside: the running maxima stay in their
+    // registers; with the row's last, partial steps in the same loop the two ways through a step were merged by
+    // eight register copies per step) ...
+    for (; q + 224 < L2; q += 256) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int qn = q + 64 * k + 192 < qend ? q + 64 * k + 192 : q + 64 * k;
+        g[(k + 3) & 3] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, grow + 4 * qn, 0);
+        i32x2 a0, a1;
+        mfma_build_a(g[k], a0, a1);
+        mfma_tiles16(a0, a1, B, m);
+      }
+    }
+    // ... then the row's last one to four steps, the last of which may be half a step
+    if (q < qend) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         // (past the row's end the request repeats this step's own run, which the wave read three
         // steps ago and the CU's cache still holds: the loads stay unconditional, so the compiler
         // counts them exactly, and none is still in flight when the next offset waits for its rows)
         const int qn = q + 64 * k + 192 < qend ? q + 64 * k + 192 : q + 64 * k;
-        g[(k + 3) & 3] = __builtin_amdgcn_raw_buffer_load_b32(rows, 4 * (qn + lane), grow, 0);
+        g[(k + 3) & 3] = __builtin_amdgcn_raw_buffer_load_b32(rows, vl, grow + 4 * qn, 0);
         if (q + 64 * k < qend) {
           i32x2 a0, a1;
           mfma_build_a(g[k], a0, a1);
