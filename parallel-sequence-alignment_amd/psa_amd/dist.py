@@ -84,17 +84,44 @@ def gather_results(local_results, my_indices, n_total, group=None):
 
 def allgather_bytes(group=None):
     """The all-gather callback of Context.score_range_allgather over torch.distributed: every rank
-    passes the same number of bytes and gets the concatenation in rank order."""
+    passes the same number of bytes and gets the concatenation in rank order.  The exchanges of a long
+    pair sit on its step's critical path (the shards wait for the maximum over all shards before they
+    shortlist), so the buffers of each message size -- device tensors for RCCL, pinned staging on the
+    host -- are made once and the gather is one collective into one tensor."""
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
     dev = _device(group)
+    cache = {}
+
+    def buffers(n):
+        b = cache.get(n)
+        if b is None:
+            host_in = torch.empty(n, dtype=torch.uint8)
+            host_out = torch.empty(world * n, dtype=torch.uint8)
+            if dev.type == "cuda":
+                host_in, host_out = host_in.pin_memory(), host_out.pin_memory()
+                b = (host_in, host_out, torch.empty(n, dtype=torch.uint8, device=dev),
+                     torch.empty(world * n, dtype=torch.uint8, device=dev))
+            else:
+                b = (host_in, host_out, host_in, host_out)
+            cache[n] = b
+        return b
 
     def fn(send):
-        mine = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        return bytes(torch.cat(parts).cpu().numpy())
+        n = len(send)
+        host_in, host_out, mine, out = buffers(n)
+        host_in.numpy()[:] = np.frombuffer(send, dtype=np.uint8)
+        if mine is not host_in:
+            mine.copy_(host_in, non_blocking=True)
+        try:
+            dist.all_gather_into_tensor(out, mine, group=group)
+        except (RuntimeError, NotImplementedError):  # a backend without the single-tensor form
+            parts = list(out.view(world, n).unbind(0))
+            dist.all_gather(parts, mine, group=group)
+        if out is not host_out:
+            host_out.copy_(out)  # (waits for the collective on the current stream)
+        return host_out.numpy().tobytes()
     return fn
 
 
