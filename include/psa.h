@@ -170,6 +170,13 @@ int psa_batch_results(const psa_batch *b, psa_result *out);
  * the time during which a candidate-loop kernel of the enumeration stage was executing (passes of a
  * large batch overlap), and first kernel start to last kernel end */
 int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms);
+/* Diagnostic (no counterpart in the reference): where the last run of `b` sat on the GPU's time axis, in
+ * milliseconds after the start of the first kernel of the last run of `ref` (a batch of the same context that has
+ * run too; b itself for times relative to its own start).  ms[0] first enumeration kernel starts, [1] first
+ * candidate loop starts, [2] last candidate loop ends, [3] enumeration records written, [4] resolve chain starts,
+ * [5] resolve records written; entries of stages the run did not have are -1.  Batches enqueued one after the
+ * other and queried this way give the unprofiled timeline of a pipeline (tools/pipeline_timeline.py). */
+int psa_batch_event_times(const psa_batch *b, const psa_batch *ref, float ms[6]);
 /* per Seq2 of the last run: rows of its shortlist (see enum_check) and the list's state -- 0 no shortlist
  * (stage not run, switched off, invalid Seq2), 1 complete and replayed, 2 overflowed.  Either array may be
  * NULL.  No counterpart in the reference. */

@@ -1238,6 +1238,31 @@ int psa_batch_timing(const psa_batch *b, float *enum_kernel_ms, float *total_ms)
   return PSA_OK;
 }
 
+int psa_batch_event_times(const psa_batch *b, const psa_batch *ref, float ms[6]) {
+  if (!b || !ref || !ms) return PSA_ERR_ARG;
+  if (!b->ran || !ref->ran || b->ctx != ref->ctx || !b->ctx) return PSA_ERR_STATE;
+  hipEvent_t origin = ref->pending_timed ? ref->ev_first : ref->ev_res_first;
+  for (int i = 0; i < 6; ++i) ms[i] = -1.f;
+  if (!origin) return PSA_ERR_STATE;
+  auto at = [&](hipEvent_t e, float *out) {
+    float t = 0.f;
+    if (e && hipEventElapsedTime(&t, origin, e) == hipSuccess) *out = t;
+  };
+  if (b->pending_timed && !b->passes.empty()) {
+    const psa_batch::SlabPass &first = b->passes.front(), &last = b->passes.back();
+    at(b->ev_first, &ms[0]);
+    at(first.ev_b[first.last_buf], &ms[1]);
+    at(last.ev_e[last.last_buf], &ms[2]);
+    at(b->ev_last, &ms[3]);
+  }
+  if (b->pending_resolve) {
+    at(b->ev_res_first, &ms[4]);
+    at(b->ev_res, &ms[5]);
+  }
+  (void)hipGetLastError();
+  return PSA_OK;
+}
+
 int psa_score_batch(psa_ctx *c, int n, const char *const *seq2, const int32_t *len2, uint32_t stages,
                     psa_result *out) {
   psa_batch *b = nullptr;

@@ -89,6 +89,7 @@ def lib():
     L.psa_batch_wait.argtypes = [vp]
     L.psa_batch_results.argtypes = [vp, C.POINTER(Result)]
     L.psa_batch_timing.argtypes = [vp, f32p, f32p]
+    L.psa_batch_event_times.argtypes = [vp, vp, f32p]
     L.psa_batch_shortlist.argtypes = [vp, i32p, i32p]
     L.psa_batch_size.argtypes = [vp]
     L.psa_batch_passes.argtypes = [vp]
@@ -420,6 +421,12 @@ class Batch:
         a, b = C.c_float(), C.c_float()
         _check(lib().psa_batch_timing(self._h, C.byref(a), C.byref(b)), "psa_batch_timing")
         return a.value, b.value
+
+    def event_times(self, ref=None):
+        """Six times (ms) of the last run on the GPU's time axis, relative to the start of `ref`'s last run."""
+        out = (C.c_float * 6)()
+        _check(lib().psa_batch_event_times(self._h, (ref or self)._h, out), "psa_batch_event_times")
+        return list(out)
 
     def close(self):
         if self._h:
