@@ -1014,6 +1014,37 @@ def test_stream_of_batches(psa, oracle):
     c.close()
 
 
+def test_event_times_of_a_pipeline(psa, oracle):
+    """psa_batch_event_times: four batches enqueued one after the other report where their runs sat on the GPU's
+    time axis -- ordered, inside the span psa_batch_timing gives, and -1 for a stage the run did not have."""
+    seq1, seq2s = synth_problem(17, 1500, [700, 300])
+    c = psa.Context(0)
+    c.set_seq1(seq1)
+    c.set_weights(np.array([2, 1.5, 1.1, 1.3], dtype=np.float32))
+    bs = [c.batch(seq2s) for _ in range(4)]
+    for b in bs:
+        b.run()
+    for b in bs:
+        b.enqueue()
+    for b in bs:
+        b.wait()
+    starts = []
+    for b in bs:
+        t = b.event_times(bs[0])
+        own = b.event_times()
+        assert own[0] == 0.0 and all(x >= 0.0 for x in t), (t, own)
+        assert t[0] <= t[1] <= t[2] <= t[3] and t[4] <= t[5], t
+        assert max(own) <= b.timing()[1] + 1e-3, (own, b.timing())
+        starts.append(t[1])
+    assert starts == sorted(starts), starts
+    bs[1].run(psa.STAGE_RESOLVE)
+    t = bs[1].event_times()
+    assert t[:4] == [-1.0] * 4 and 0.0 <= t[4] <= t[5], t
+    with pytest.raises(psa.PsaError):
+        c.batch(seq2s).event_times()  # has not run
+    c.close()
+
+
 def test_clock_probe_variant(psa, oracle):
     """The stamped variant of the candidate loop returns the same records as the plain one, and the
     clock it reports is a shader clock this chip can hold."""
