@@ -636,6 +636,25 @@ def host_inclusive(ctx, seq1, seq2s, calls=20):
             ctx.score_batch(seq2s, st)
         ms = 1e3 * (time.perf_counter() - t0) / calls
         out[label] = {"ms_per_call": ms, "candidates_per_s": cand / ms * 1e3}
+    # a caller that streams: a FRESH batch per call (created from host buffers, uploaded, scored with both stages,
+    # records read, released), the next one enqueued before the last is awaited -- three in flight
+    for rep in range(2):
+        queue, n = [], 10 * calls
+        t0 = time.perf_counter()
+        for _ in range(n):
+            b = ctx.batch(seq2s)
+            b.enqueue(psa_amd.STAGE_BOTH)
+            queue.append(b)
+            if len(queue) >= 3:
+                o = queue.pop(0)
+                o.wait()
+                o.results()
+                o.close()
+        for o in queue:
+            o.wait()
+            o.close()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+    out["fresh_batches_streamed_three_deep_both_stages"] = {"ms_per_batch": ms, "candidates_per_s": cand / ms * 1e3}
     os.environ["PSA_SHIM_QUIET"] = "1"
     table = psa_amd.createCompMatrix(WEIGHTS)
     psa_amd.calc_best_score(seq1, seq2s[0], table)
